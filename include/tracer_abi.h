@@ -1,0 +1,159 @@
+/* include/tracer_abi.h -- C ABI of libtracer_amd.so, the MI355X (gfx950) replacement for the
+ * per-bounce path-tracing loop of nopjia/tracer.
+ *
+ * What it replaces (paths relative to the reference checkout):
+ *   src/raytrace.cu:189-238   extern "C" pathtrace() / raytrace1() kernel launchers
+ *   src/raytrace.cu:29-187    the kernels behind them
+ *   src/Renderer.cpp:94-151   device buffer ownership + deep-copied scene upload
+ *   src/Renderer.cpp:173-206  CUDA-GL PBO mapping (replaced by a headless buffer)
+ * The reference binds this path from C++ (Renderer.cpp:7-23 declares the two extern "C"
+ * launchers and Renderer::render calls them, Renderer.cpp:177-191). INTEGRATION.md shows the
+ * Renderer.cpp a maintainer would write on top of this header.
+ *
+ * Conventions
+ *   - every call returns 0 on success or a non-zero trc_status; trc_last_error_string() gives
+ *     the text. Nothing here calls exit() (the reference's checkCudaErrors does).
+ *   - plain pointers and sizes only. `objects` is the caller's HOST array of Object::Object in
+ *     the reference's own memory layout (Object.inl:24-29; LP64: 168 bytes, m_mesh -> Mesh::Mesh
+ *     of Mesh.inl:34-41, 72 bytes). It is read during the call and not retained.
+ *   - a context is bound to one GPU and one HIP stream; calls on one context are not
+ *     re-entrant. Rendering calls are asynchronous on that stream; the trc_read_* calls and
+ *     trc_synchronize() wait for it.
+ *   - `iter` is the reference's 1-based filmIters (Renderer.cpp:183). The film is the
+ *     un-normalised running sum of per-iteration radiance (raytrace.cu:170) and is zeroed
+ *     when iteration 1 is rendered (raytrace.cu:103-104).
+ */
+#ifndef TRACER_ABI_H
+#define TRACER_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trc_ctx trc_ctx;
+
+typedef enum trc_status {
+  TRC_OK = 0,
+  TRC_ERR_INVALID = 1,   /* bad argument (null pointer, zero size, index out of range, ...) */
+  TRC_ERR_HIP = 2,       /* a HIP runtime call failed; see trc_last_error_string() */
+  TRC_ERR_NO_SCENE = 3,  /* render call before trc_upload_scene */
+  TRC_ERR_UNSUPPORTED = 4
+} trc_status;
+
+/* Camera frame as Renderer::render computes it (Renderer.cpp:156-171) and passes it to the
+ * launchers (raytrace.cu:192-193): position, screen-x / screen-y half extents A and B
+ * (already scaled by tan(fov) and 1/aspect), view direction C, thin-lens parameters
+ * (Camera.h:32-33). */
+typedef struct trc_camera {
+  float campos[3];
+  float A[3];
+  float B[3];
+  float C[3];
+  float lensRadius;
+  float focalDist;
+} trc_camera;
+
+/* Per-bounce random triple (raytrace.cu:155-157):
+ *  TRC_RNG_REFERENCE     rand[randidx] of the same iteration, randidx = (idx + (int)dot(dir,pos)) % N,
+ *                        i.e. the reference's reuse of one triple per pixel per iteration;
+ *  TRC_RNG_DECORRELATED  an independent triple per (pixel, iteration, depth).            */
+typedef enum trc_rng_mode { TRC_RNG_REFERENCE = 0, TRC_RNG_DECORRELATED = 1 } trc_rng_mode;
+
+/* How one pathtrace call is executed on the GPU (results are bit-identical across all three):
+ *  TRC_PIPE_WAVEFRONT   one raygen launch, PATH_DEPTH bounce launches over per-pixel ray state
+ *                       in HBM, one accumulate launch per iteration (the reference's structure,
+ *                       raytrace.cu:211-225), dead paths skipped by flag;
+ *  TRC_PIPE_COMPACTED   same, but live paths are compacted into a queue after every bounce by
+ *                       wavefront ballot (README.md:56 "stream compaction");
+ *  TRC_PIPE_FUSED       one persistent launch per call: ray state stays in registers across
+ *                       bounces and iterations, finished lanes regenerate the next sample.  */
+typedef enum trc_pipeline { TRC_PIPE_WAVEFRONT = 0, TRC_PIPE_COMPACTED = 1, TRC_PIPE_FUSED = 2 } trc_pipeline;
+
+typedef enum trc_option {
+  TRC_OPT_RNG_MODE = 0,     /* trc_rng_mode, default TRC_RNG_REFERENCE */
+  TRC_OPT_PIPELINE = 1,     /* trc_pipeline, default TRC_PIPE_FUSED */
+  TRC_OPT_RECORD_HITS = 2   /* 0/1: raytrace1 also stores id/t/pos/nor per pixel (default 1) */
+} trc_option;
+
+/* Device-side event counts since the last trc_reset_counters (units of SURVEY.md 8d). */
+typedef struct trc_counters {
+  uint64_t live_segments;   /* closest-hit evaluations for live paths (raytrace.cu:119-127) */
+  uint64_t paths;           /* camera rays generated (pixels x iterations) */
+  uint64_t tri_tests;       /* ray-triangle tests executed (Ray.inl:173) */
+} trc_counters;
+
+/* ---- life cycle (replaces Renderer::initCUDAMemory/freeCUDAMemory, Renderer.cpp:94-110) -- */
+/* `stream`: a hipStream_t to launch on, or NULL to create a private one. */
+int trc_create(int device, uint32_t width, uint32_t height, void* stream, trc_ctx** out);
+int trc_destroy(trc_ctx* ctx);
+int trc_set_option(trc_ctx* ctx, int option, int value);
+
+/* ---- scene (replaces Renderer::initScene / updateScene, Renderer.cpp:112-151, :221-225) -- */
+int trc_upload_scene(trc_ctx* ctx, const void* objects, uint32_t count);
+/* matrix / inverse as 16 floats each, column-major (glm::mat4 memory order). */
+int trc_update_object(trc_ctx* ctx, uint32_t index, const float matrix[16], const float matrixi[16]);
+
+/* ---- rendering (replaces raytrace1 / pathtrace, raytrace.cu:189-238) -------------------- */
+/* mode 1: one closest-hit + flat shade per pixel into the LDR buffer (raytrace.cu:29-62). */
+int trc_raytrace1(trc_ctx* ctx, const trc_camera* cam);
+/* mode 2: iterations iter_first, iter_first + iter_stride, ... (n_iters of them) accumulated
+ * into the film; the LDR buffer then holds rgbToInt(pow(film / last_iter, 1/2.2)) as after the
+ * reference's last accumColorKernel (raytrace.cu:173). seed keys the RNG (rng.h).          */
+int trc_pathtrace(trc_ctx* ctx, const trc_camera* cam, uint64_t seed,
+                  uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters);
+/* Renderer::resetFilm (Renderer.cpp:209-211); also zeroes the film buffer itself so that a
+ * rank that never renders iteration 1 starts from zero. */
+int trc_reset_film(trc_ctx* ctx);
+/* LDR buffer = rgbToInt(pow(film / iters, 1/2.2)) (raytrace.cu:173), e.g. after a multi-GPU sum. */
+int trc_tonemap(trc_ctx* ctx, float iters);
+
+/* ---- headless output (replaces the PBO -> texture path, Renderer.cpp:193-206) ----------- */
+int trc_read_film(trc_ctx* ctx, float* rgb /* 3*w*h */);
+int trc_write_film(trc_ctx* ctx, const float* rgb /* 3*w*h */);   /* resume from a checkpoint */
+int trc_read_ldr(trc_ctx* ctx, uint32_t* bgra /* w*h, 0x00RRGGBB as rgbToInt packs it */);
+/* validation outputs of the last trc_raytrace1; any pointer may be NULL. */
+int trc_read_hits(trc_ctx* ctx, int32_t* ids, float* ts, float* pos3, float* nor3);
+int trc_synchronize(trc_ctx* ctx);
+
+/* The film as a device pointer (3*w*h floats), for a sum-reduce over RCCL by the caller. */
+int trc_film_device_ptr(trc_ctx* ctx, void** dev_ptr);
+/* Use caller-owned device memory (3*w*h floats, 16-byte aligned) as the film from now on;
+ * NULL returns to the context's own buffer. */
+int trc_bind_film(trc_ctx* ctx, void* dev_ptr);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+int trc_get_counters(trc_ctx* ctx, trc_counters* out);   /* waits for the stream */
+int trc_reset_counters(trc_ctx* ctx);
+/* GPU time of the last trc_raytrace1 / trc_pathtrace call between HIP events recorded on the
+ * context's stream around its launches (waits for it). */
+int trc_last_render_ms(trc_ctx* ctx, float* ms);
+/* Same, up to the end of the path kernels only (excludes the display transform): for
+ * TRC_PIPE_FUSED this is the duration of the single persistent launch. */
+int trc_last_kernel_ms(trc_ctx* ctx, float* ms);
+
+const char* trc_last_error_string(void);
+const char* trc_version(void);
+
+/* ---- the reference's own launcher signatures (raytrace.cu:189-199, :228-232) ------------- */
+/* Same argument lists as the reference; glm::vec3 references are `const float*` at the ABI.
+ * All buffers are DEVICE pointers owned by the caller exactly as Renderer.cpp allocates them
+ * (Renderer.cpp:94-100), in the reference's layouts; `scene_d` is the device copy of Object[]
+ * produced by Renderer::initScene (Renderer.cpp:112-151). `time` seeds the RNG as
+ * (uint64)(time*100.0f) like curandSetPseudoRandomGeneratorSeed (raytrace.cu:205);
+ * `rand_d` is accepted and left untouched (the RNG is counter-based).                     */
+void pathtrace(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
+               const float* campos, const float* A, const float* B, const float* C,
+               float lensRadius, float focalDist,
+               const void* scene_d, uint32_t sceneSize,
+               void* rand_d, void* rays_d, void* col_d, int* idx_d,
+               void* film_d, uint32_t filmIters);
+void raytrace1(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
+               const float* campos, const float* A, const float* B, const float* C,
+               const void* scene_d, uint32_t sceneSize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACER_ABI_H */

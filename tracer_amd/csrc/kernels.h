@@ -1,0 +1,58 @@
+// tracer_amd/csrc/kernels.h -- launch interface between the C ABI (tracer_abi.cpp) and the
+// gfx950 kernels (kernels.hip).
+#pragma once
+#include "scene.h"
+#include <hip/hip_runtime.h>
+
+namespace trc {
+
+// Everything a kernel needs that is uniform over the launch. Passed by value (kernarg
+// segment -> SGPRs).
+struct FrameParams {
+  uint32_t w, h, npix;
+  f3 campos, A, B, C;       // raytrace.cu:192
+  f3 nA, nB;                // normalize(A), normalize(B) of raytrace.cu:94, hoisted to the host
+  float lensRadius, focalDist;
+  const DevObject* objs;    // scene records (scene.h)
+  const DevTri* tris;       // triangle stream
+  uint32_t nobj;
+  uint32_t seed_lo, seed_hi;
+  int rng_mode;             // trc_rng_mode
+};
+
+// Per-path state of the wavefront pipelines, planar (one float per lane per plane, so every
+// load/store instruction of a wavefront covers 256 contiguous bytes). Two of these are
+// ping-ponged by the compacting pipeline.
+struct PathState {
+  float* px; float* py; float* pz;     // ray origin      (Ray::m_pos)
+  float* dx; float* dy; float* dz;     // ray direction   (Ray::m_dir)
+  float* cr; float* cg; float* cb;     // throughput      (col_d)
+  int32_t* pixel;                      // owning pixel, or -1 once terminated (idx_d)
+};
+
+struct DeviceCounters {
+  unsigned long long live_segments;
+  unsigned long long paths;
+  unsigned long long tri_tests;
+};
+
+// mode 1 (raytrace.cu:29-62). hit_* may be null.
+void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, float* hit_t,
+                      float* hit_pos, float* hit_nor, hipStream_t stream);
+
+// mode 2, wavefront pipelines: one iteration = raygen + kPathDepth bounce launches.
+// compact = false: state stays at slot == pixel, dead paths flagged (pixel plane = -1).
+// compact = true : survivors are written densely into `next` behind a wave-ballot prefix sum;
+//                  queue_count[d] is the number of live paths entering bounce d.
+void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compact,
+                                PathState cur, PathState next, uint32_t* queue_count /*[kPathDepth+1]*/,
+                                float* film, DeviceCounters* counters, hipStream_t stream);
+
+// mode 2, fused persistent pipeline: all iterations of the call in one launch.
+void launch_fused(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
+                  float* film, DeviceCounters* counters, hipStream_t stream);
+
+// display transform (raytrace.cu:173) over the whole film.
+void launch_tonemap(const float* film, uint32_t npix, float iters, uint32_t* ldr, hipStream_t stream);
+
+} // namespace trc

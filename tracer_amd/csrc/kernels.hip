@@ -1,0 +1,288 @@
+// tracer_amd/csrc/kernels.hip -- hand-written gfx950 kernels for the per-bounce path-tracing
+// loop (replaces reference src/raytrace.cu:29-177). Compiled with -ffp-contract=off.
+//
+// Three pipelines produce bit-identical films (tracer_abi.h: trc_pipeline):
+//   wavefront : per-pixel ray state in HBM, one launch per bounce (reference structure)
+//   compacted : same, survivors compacted by wavefront ballot into a dense queue each bounce
+//   fused     : one persistent launch; state lives in VGPRs across bounces and iterations
+// The film sum of a pixel is always iteration 1, 2, 3, ... in that order (raytrace.cu:170),
+// and adding the black (0,0,0) of a missed / depth-capped path is skipped because x + 0 == x.
+#include "kernels.h"
+#include "intersect.h"
+#include "shade.h"
+#include "rng.h"
+
+#pragma clang fp contract(off)
+
+namespace trc {
+
+constexpr int kBlock = 256;
+
+// ---- wave64 helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ void count_add(unsigned long long* dst, unsigned long long lane_value) {
+  unsigned long long s = wave_sum_u64(lane_value);
+  if (lane_id() == 0 && s) atomicAdd(dst, s);
+}
+
+// ---- camera rays ------------------------------------------------------------------------------
+// raytrace.cu:40-43 (mode 1: pixel corner, no jitter, pinhole)
+__device__ __forceinline__ Ray primary_ray(const FrameParams& fp, uint32_t idx) {
+  uint32_t x = idx % fp.w;
+  uint32_t y = idx / fp.w;
+  float u = (float)x / fp.w, v = (float)y / fp.h;
+  Ray ray;
+  ray.pos = fp.campos + fp.C + (2.0f * u - 1.0f) * fp.A + (2.0f * v - 1.0f) * fp.B;
+  ray.dir = normalize(ray.pos - fp.campos);
+  return ray;
+}
+
+// initBuffersKernel, raytrace.cu:72-96: +-1 pixel jitter and thin-lens depth of field, all
+// from the one triple rand[idx] (x, y reused by jitter and lens).
+__device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx, uint32_t iter) {
+  uint32_t x = idx % fp.w;
+  uint32_t y = idx / fp.w;
+  f3 r = rand3(fp.seed_lo, fp.seed_hi, idx, iter, 0u);
+  float u = (float)x / fp.w + (2.0f * r.x - 1.0f) / fp.w;
+  float v = (float)y / fp.h + (2.0f * r.y - 1.0f) / fp.h;
+  Ray ray;
+  ray.pos = fp.campos + fp.C + (2.0f * u - 1.0f) * fp.A + (2.0f * v - 1.0f) * fp.B;
+  ray.dir = normalize(ray.pos - fp.campos);
+  f3 fpt = fp.focalDist * ray.dir + ray.pos;
+  f2 disk = rand_point_disk(r.x, r.y, r.z);
+  float dkx = fp.lensRadius * disk.x, dky = fp.lensRadius * disk.y;
+  ray.pos = ray.pos + (dky * fp.nA + dkx * fp.nB);          // note the x/y swap, raytrace.cu:94
+  ray.dir = normalize(fpt - ray.pos);
+  return ray;
+}
+
+// ---- one bounce (calcColorKernel body, raytrace.cu:126-159) -------------------------------------
+enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2 };
+
+__device__ __forceinline__ int bounce_step(const FrameParams& fp, uint32_t pixel, uint32_t iter, int depth,
+                                           Ray& ray, f3& col, uint32_t& tri_tests) {
+  Hit hit = closest_hit(ray, fp.objs, fp.nobj, fp.tris, tri_tests);
+  if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
+  const DevObject& o = fp.objs[hit.id];
+  const f3 mcolor = o.color;
+  const float emit = o.emit;
+  if (emit > 0.0f) { col = col * (mcolor * emit); return STEP_LIGHT; }      // :137-141
+  if (depth == kPathDepth - 1) { col = splat3(0.0f); return STEP_BLACK; }   // :144-147
+  col = col * mcolor;                                                      // :151
+  f3 rnd;
+  if (fp.rng_mode == 0) {
+    // :155 -- unsigned wrap-around of idx + (int)dot, then % size; ray is the PRE-bounce ray
+    uint32_t randidx = (pixel + (uint32_t)(int)dot(ray.dir, ray.pos)) % fp.npix;
+    rnd = rand3(fp.seed_lo, fp.seed_hi, randidx, iter, 0u);
+  } else {
+    rnd = rand3(fp.seed_lo, fp.seed_hi, pixel, iter, 1u + (uint32_t)depth);
+  }
+  ray.dir = bounce(o.mat_type, o.ior, ray.dir, hit.nor, rnd);              // :156-157
+  ray.pos = hit.pos + kEps * ray.dir;                                      // :159
+  return STEP_CONTINUE;
+}
+
+// ---- mode 1: raytraceKernel, raytrace.cu:29-62 ---------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* __restrict__ ldr,
+                                                     int32_t* __restrict__ hit_id, float* __restrict__ hit_t,
+                                                     float* __restrict__ hit_pos, float* __restrict__ hit_nor) {
+  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= fp.npix) return;
+  Ray ray = primary_ray(fp, idx);
+  uint32_t tt = 0;
+  Hit hit = closest_hit(ray, fp.objs, fp.nobj, fp.tris, tt);
+  const f3 lightDir = mk3((float)0.267261, (float)0.801784, (float)0.534522);
+  f3 col;
+  if (hit.id < 0) col = ray.dir;
+  else {
+    const DevObject& o = fp.objs[hit.id];
+    if (o.emit > 0.0f) col = o.color;
+    else {
+      col = o.color * o.brdf;
+      col = col * gmax(dot(lightDir, hit.nor), 0.0f);
+    }
+  }
+  ldr[idx] = rgb_to_int(col);
+  if (hit_id) hit_id[idx] = hit.id;
+  if (hit_t) hit_t[idx] = hit.t;
+  if (hit_pos) { hit_pos[3 * idx] = hit.pos.x; hit_pos[3 * idx + 1] = hit.pos.y; hit_pos[3 * idx + 2] = hit.pos.z; }
+  if (hit_nor) { hit_nor[3 * idx] = hit.nor.x; hit_nor[3 * idx + 1] = hit.nor.y; hit_nor[3 * idx + 2] = hit.nor.z; }
+}
+
+// ---- wavefront pipelines -------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter, PathState st,
+                                                  uint32_t* __restrict__ queue_count,
+                                                  float* __restrict__ film, DeviceCounters* counters) {
+  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx == 0) {
+    queue_count[0] = fp.npix;
+#pragma unroll
+    for (int d = 1; d <= kPathDepth; ++d) queue_count[d] = 0;
+  }
+  const bool valid = idx < fp.npix;
+  if (valid) {
+    Ray ray = camera_sample(fp, idx, iter);
+    st.px[idx] = ray.pos.x; st.py[idx] = ray.pos.y; st.pz[idx] = ray.pos.z;
+    st.dx[idx] = ray.dir.x; st.dy[idx] = ray.dir.y; st.dz[idx] = ray.dir.z;
+    st.cr[idx] = 1.0f; st.cg[idx] = 1.0f; st.cb[idx] = 1.0f;           // raytrace.cu:99
+    st.pixel[idx] = (int32_t)idx;                                     // :101
+    if (iter == 1) { film[3 * idx] = 0.0f; film[3 * idx + 1] = 0.0f; film[3 * idx + 2] = 0.0f; } // :103
+  }
+  count_add(&counters->paths, valid ? 1ull : 0ull);
+}
+
+template <bool COMPACT>
+__global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter, int depth,
+                                                  PathState cur, PathState next,
+                                                  const uint32_t* __restrict__ count_in,
+                                                  uint32_t* __restrict__ count_out,
+                                                  float* __restrict__ film, DeviceCounters* counters) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t n_in = COMPACT ? *count_in : fp.npix;
+  if (blockIdx.x * kBlock >= n_in) return;                            // whole block past the queue
+  int32_t pixel = (i < n_in) ? cur.pixel[i] : -1;
+  const bool active = pixel >= 0;                                     // raytrace.cu:119-124
+  bool cont = false;
+  Ray ray; f3 col = splat3(0.0f);
+  uint32_t tt = 0;
+  if (active) {
+    ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]);
+    ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
+    col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
+    int res = bounce_step(fp, (uint32_t)pixel, iter, depth, ray, col, tt);
+    cont = (res == STEP_CONTINUE);
+    if (res == STEP_LIGHT) {                                          // the only non-black ending
+      film[3 * pixel] += col.x; film[3 * pixel + 1] += col.y; film[3 * pixel + 2] += col.z;
+    }
+  }
+  if (COMPACT) {
+    // compaction by wavefront ballot: rank within the wave from the ballot mask, one atomic
+    // per wave reserves a contiguous run in the next queue.
+    const unsigned long long mask = __ballot(cont);
+    const unsigned lane = lane_id();
+    const unsigned total = __popcll(mask);
+    unsigned base = 0;
+    if (lane == 0 && total) base = atomicAdd(count_out, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (cont) {
+      const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+      const uint32_t j = base + rank;
+      next.px[j] = ray.pos.x; next.py[j] = ray.pos.y; next.pz[j] = ray.pos.z;
+      next.dx[j] = ray.dir.x; next.dy[j] = ray.dir.y; next.dz[j] = ray.dir.z;
+      next.cr[j] = col.x; next.cg[j] = col.y; next.cb[j] = col.z;
+      next.pixel[j] = pixel;
+    }
+  } else if (active) {
+    if (cont) {
+      cur.px[i] = ray.pos.x; cur.py[i] = ray.pos.y; cur.pz[i] = ray.pos.z;
+      cur.dx[i] = ray.dir.x; cur.dy[i] = ray.dir.y; cur.dz[i] = ray.dir.z;
+      cur.cr[i] = col.x; cur.cg[i] = col.y; cur.cb[i] = col.z;
+    } else {
+      cur.pixel[i] = -1;                                              // raytrace.cu:132,139
+    }
+  }
+  count_add(&counters->live_segments, active ? 1ull : 0ull);
+  count_add(&counters->tri_tests, (unsigned long long)tt);
+}
+
+// ---- fused persistent pipeline ------------------------------------------------------------------
+// One lane owns one pixel for the whole call. Its ray, throughput and film sum stay in VGPRs;
+// a lane whose path ended starts that pixel's next iteration at once (path regeneration), so
+// every trip of the loop is one closest-hit evaluation for (nearly) all 64 lanes.
+__global__ __launch_bounds__(kBlock) void k_fused(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
+                                                 uint32_t n_iters, float* __restrict__ film,
+                                                 DeviceCounters* counters) {
+  const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = pixel < fp.npix;
+  f3 acc = splat3(0.0f);
+  if (valid) acc = mk3(film[3 * pixel], film[3 * pixel + 1], film[3 * pixel + 2]);
+  uint32_t k = 0;                 // iterations of this call already accumulated
+  uint32_t iter = iter_first;
+  int depth = 0;
+  bool need_new = true;
+  bool done = !valid || n_iters == 0;
+  Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
+  f3 col = splat3(0.0f);
+  uint32_t live = 0, tt = 0;
+
+  while (true) {
+    if (!done && need_new) {
+      iter = iter_first + k * iter_stride;
+      if (iter == 1) acc = splat3(0.0f);                              // raytrace.cu:103-104
+      ray = camera_sample(fp, pixel, iter);
+      col = splat3(1.0f);
+      depth = 0;
+      need_new = false;
+    }
+    if (__ballot(!done) == 0ull) break;
+    if (!done) {
+      ++live;
+      int res = bounce_step(fp, pixel, iter, depth, ray, col, tt);
+      if (res == STEP_CONTINUE) {
+        ++depth;
+      } else {
+        if (res == STEP_LIGHT) acc = acc + col;                       // film += col, raytrace.cu:170
+        ++k;
+        need_new = true;
+        done = (k == n_iters);
+      }
+    }
+  }
+  if (valid) { film[3 * pixel] = acc.x; film[3 * pixel + 1] = acc.y; film[3 * pixel + 2] = acc.z; }
+  count_add(&counters->live_segments, (unsigned long long)live);
+  count_add(&counters->tri_tests, (unsigned long long)tt);
+  count_add(&counters->paths, valid ? (unsigned long long)n_iters : 0ull);
+}
+
+// ---- display transform, raytrace.cu:173 -----------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float* __restrict__ film, uint32_t npix, float iters,
+                                                   uint32_t* __restrict__ ldr) {
+  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= npix) return;
+  ldr[idx] = tonemap(mk3(film[3 * idx], film[3 * idx + 1], film[3 * idx + 2]), iters);
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+static inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, float* hit_t,
+                      float* hit_pos, float* hit_nor, hipStream_t stream) {
+  hipLaunchKernelGGL(k_raytrace1, dim3(grid_for(fp.npix)), dim3(kBlock), 0, stream,
+                     fp, ldr, hit_id, hit_t, hit_pos, hit_nor);
+}
+
+void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compact,
+                                PathState cur, PathState next, uint32_t* queue_count,
+                                float* film, DeviceCounters* counters, hipStream_t stream) {
+  const dim3 grid(grid_for(fp.npix)), block(kBlock);
+  hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter, cur, queue_count, film, counters);
+  for (int d = 0; d < kPathDepth; ++d) {
+    if (compact) {
+      hipLaunchKernelGGL(k_bounce<true>, grid, block, 0, stream, fp, iter, d, cur, next,
+                         queue_count + d, queue_count + d + 1, film, counters);
+      PathState t = cur; cur = next; next = t;
+    } else {
+      hipLaunchKernelGGL(k_bounce<false>, grid, block, 0, stream, fp, iter, d, cur, cur,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, film, counters);
+    }
+  }
+}
+
+void launch_fused(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
+                  float* film, DeviceCounters* counters, hipStream_t stream) {
+  hipLaunchKernelGGL(k_fused, dim3(grid_for(fp.npix)), dim3(kBlock), 0, stream,
+                     fp, iter_first, iter_stride, n_iters, film, counters);
+}
+
+void launch_tonemap(const float* film, uint32_t npix, float iters, uint32_t* ldr, hipStream_t stream) {
+  hipLaunchKernelGGL(k_tonemap, dim3(grid_for(npix)), dim3(kBlock), 0, stream, film, npix, iters, ldr);
+}
+
+} // namespace trc

@@ -1,0 +1,71 @@
+// tracer_amd/csrc/scene.h -- scene description as the caller hands it over (the reference's
+// pointer-based AoS) and as the kernels read it (flat, pointer-free, wave-uniform records).
+#pragma once
+#include "vecmath.h"
+
+namespace trc {
+
+// ---- constants that are part of the contract: reference src/common.h:31,37,40,41 ----------
+constexpr float kEps = 0.001f;        // EPS
+constexpr int   kPathDepth = 5;       // PATH_DEPTH
+constexpr float kPi = 3.14159265358979323846264338327950288f;  // common.h:17 (float M_PI)
+
+// ---- caller-side layout (host memory), mirrors of the reference's structs -----------------
+// Object.inl:24-29, Mesh.inl:22-41, Material.inl:19-34 on LP64. Only read, never written.
+enum RefMeshType { REF_MESH = 0, REF_SPHERE = 1, REF_CUBE = 2, REF_PLANE = 3 };   // Mesh.inl:32
+enum RefMatType  { REF_DIFF = 0, REF_TRANS = 1, REF_MIRR = 2 };                  // Material.inl:19
+
+struct RefFace { uint32_t v[3]; uint32_t n[3]; };
+struct RefMesh {
+  uint32_t numVerts, numNorms, numFaces;
+  f3* verts; f3* norms; RefFace* faces;
+  f3 bmin, bmax;
+  int32_t type;
+};
+struct RefMaterial { f3 color; float emit, brdf, n; int32_t type; };
+struct RefObject {
+  float matrix[16];   // glm::mat4, column-major
+  float matrixi[16];
+  RefMesh* mesh;
+  RefMaterial material;
+};
+static_assert(sizeof(RefFace) == 24, "Mesh::Face layout");
+static_assert(sizeof(RefMesh) == 72, "Mesh::Mesh layout");
+static_assert(sizeof(RefMaterial) == 28, "Material::Material layout");
+static_assert(sizeof(RefObject) == 168, "Object::Object layout");
+
+// ---- device-side layout -------------------------------------------------------------------
+// One 160-byte record per object, read with wave-uniform (scalar) loads: every lane of a
+// wavefront walks the same object list (Ray.inl:70), so the record lives in SGPRs.
+struct alignas(16) DevObject {
+  Affine   mi;           // world -> object, 12 floats   (Object::m_matrixi)
+  Affine   m;            // object -> world, 12 floats   (Object::m_matrix)
+  f3       bmin;         // MESH only (Mesh::m_bmin/m_bmax)
+  uint32_t tri_first;    // first record in the triangle stream
+  f3       bmax;
+  uint32_t tri_count;    // Mesh::m_numFaces
+  f3       color;        // Material::m_color
+  float    emit;         // Material::m_emit
+  float    brdf;         // Material::m_brdf
+  float    ior;          // Material::m_n
+  int32_t  mat_type;     // RefMatType
+  int32_t  mesh_type;    // RefMeshType
+};
+static_assert(sizeof(DevObject) == 160, "DevObject");
+
+// Triangle stream: faces pre-gathered at upload (replaces the Face -> verts/norms double
+// indirection of Mesh::getTriangle, Mesh.inl:50-65) into 80-byte records that are contiguous
+// in HBM, so a tile of T triangles is one coalesced T*80-byte copy into LDS and one record is
+// five 16-byte broadcast reads. e1 = v1 - v0 and e2 = v2 - v0 (Ray.inl:190-191) are the same
+// IEEE subtractions the reference performs per ray, done once here.
+struct alignas(16) DevTri {
+  f3 v0; f3 e1; f3 e2;
+  f3 n0; f3 n1; f3 n2;
+  float pad[2];
+};
+static_assert(sizeof(DevTri) == 80, "DevTri");
+
+struct Ray { f3 pos, dir; };
+struct Hit { float t; int id; f3 pos, nor; };
+
+} // namespace trc

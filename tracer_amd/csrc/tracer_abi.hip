@@ -1,0 +1,562 @@
+// tracer_amd/csrc/tracer_abi.hip -- implementation of include/tracer_abi.h: context, scene
+// flattening, launches, headless read-back. Host code only; kernels are in kernels.hip.
+//
+// Replaces reference src/Renderer.cpp:94-151 (buffer ownership, scene deep copy), :173-206
+// (PBO map/unmap) and src/raytrace.cu:189-238 (launchers).
+#include "../../include/tracer_abi.h"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+using namespace trc;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      return fail(TRC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    }                                                                                      \
+  } while (0)
+
+template <typename T> void free_dev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+} // namespace
+
+struct trc_ctx {
+  int device = 0;
+  uint32_t w = 0, h = 0, npix = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;
+  bool timed = false;
+
+  int rng_mode = TRC_RNG_REFERENCE;
+  int pipeline = TRC_PIPE_FUSED;
+  int record_hits = 1;
+
+  // scene
+  DevObject* objs_d = nullptr;
+  DevTri* tris_d = nullptr;
+  uint32_t nobj = 0;
+  std::vector<DevObject> objs_h;
+
+  // outputs
+  float* film_own = nullptr;   // 3*npix
+  float* film = nullptr;       // film_own or a bound external buffer
+  uint32_t* ldr = nullptr;     // npix
+  int32_t* hit_id = nullptr; float* hit_t = nullptr; float* hit_pos = nullptr; float* hit_nor = nullptr;
+
+  // wavefront state (allocated on first use)
+  float* state_mem[2] = { nullptr, nullptr };
+  PathState state[2];
+  uint32_t* queue_count = nullptr;
+
+  DeviceCounters* counters = nullptr;
+};
+
+namespace {
+
+int ensure_wavefront_state(trc_ctx* c, bool need_second) {
+  for (int b = 0; b < (need_second ? 2 : 1); ++b) {
+    if (c->state_mem[b]) continue;
+    HIP_TRY(hipMalloc((void**)&c->state_mem[b], sizeof(float) * 10ull * c->npix));
+    float* p = c->state_mem[b];
+    PathState& s = c->state[b];
+    s.px = p; s.py = p + c->npix; s.pz = p + 2ull * c->npix;
+    s.dx = p + 3ull * c->npix; s.dy = p + 4ull * c->npix; s.dz = p + 5ull * c->npix;
+    s.cr = p + 6ull * c->npix; s.cg = p + 7ull * c->npix; s.cb = p + 8ull * c->npix;
+    s.pixel = (int32_t*)(p + 9ull * c->npix);
+  }
+  if (!c->queue_count) HIP_TRY(hipMalloc((void**)&c->queue_count, sizeof(uint32_t) * (kPathDepth + 1)));
+  return TRC_OK;
+}
+
+int ensure_hit_buffers(trc_ctx* c) {
+  if (c->hit_id) return TRC_OK;
+  HIP_TRY(hipMalloc((void**)&c->hit_id, sizeof(int32_t) * c->npix));
+  HIP_TRY(hipMalloc((void**)&c->hit_t, sizeof(float) * c->npix));
+  HIP_TRY(hipMalloc((void**)&c->hit_pos, sizeof(float) * 3ull * c->npix));
+  HIP_TRY(hipMalloc((void**)&c->hit_nor, sizeof(float) * 3ull * c->npix));
+  return TRC_OK;
+}
+
+f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+void affine_from_mat4(Affine& a, const float m[16]) {
+  for (int col = 0; col < 4; ++col)
+    for (int row = 0; row < 3; ++row) a.c[col][row] = m[4 * col + row];
+}
+
+FrameParams make_params(const trc_ctx* c, const trc_camera* cam, uint64_t seed) {
+  FrameParams fp;
+  fp.w = c->w; fp.h = c->h; fp.npix = c->npix;
+  fp.campos = ld3(cam->campos); fp.A = ld3(cam->A); fp.B = ld3(cam->B); fp.C = ld3(cam->C);
+  fp.nA = normalize(fp.A);       // raytrace.cu:94 evaluates these per thread; same IEEE ops here
+  fp.nB = normalize(fp.B);
+  fp.lensRadius = cam->lensRadius; fp.focalDist = cam->focalDist;
+  fp.objs = c->objs_d; fp.tris = c->tris_d; fp.nobj = c->nobj;
+  fp.seed_lo = (uint32_t)seed; fp.seed_hi = (uint32_t)(seed >> 32);
+  fp.rng_mode = c->rng_mode;
+  return fp;
+}
+
+// Flatten the caller's Object[]/Mesh AoS into DevObject records + one triangle stream.
+int flatten_scene(const RefObject* objs, uint32_t count, std::vector<DevObject>& out_objs,
+                  std::vector<DevTri>& out_tris) {
+  out_objs.resize(count);
+  out_tris.clear();
+  for (uint32_t i = 0; i < count; ++i) {
+    const RefObject& o = objs[i];
+    if (!o.mesh) return fail(TRC_ERR_INVALID, "object " + std::to_string(i) + " has a null m_mesh");
+    const RefMesh& m = *o.mesh;
+    DevObject d;
+    memset(&d, 0, sizeof d);
+    affine_from_mat4(d.mi, o.matrixi);
+    affine_from_mat4(d.m, o.matrix);
+    d.bmin = m.bmin; d.bmax = m.bmax;
+    d.color = o.material.color; d.emit = o.material.emit; d.brdf = o.material.brdf; d.ior = o.material.n;
+    d.mat_type = o.material.type;
+    d.mesh_type = m.type;
+    if (d.mesh_type < REF_MESH || d.mesh_type > REF_PLANE)
+      return fail(TRC_ERR_INVALID, "object " + std::to_string(i) + ": unknown MeshType");
+    if (d.mat_type < REF_DIFF || d.mat_type > REF_MIRR)
+      return fail(TRC_ERR_INVALID, "object " + std::to_string(i) + ": unknown Material::Type");
+    d.tri_first = (uint32_t)out_tris.size();
+    d.tri_count = 0;
+    if (d.mesh_type == REF_MESH) {
+      if (m.numFaces && (!m.verts || !m.norms || !m.faces))
+        return fail(TRC_ERR_INVALID, "object " + std::to_string(i) + ": MESH with null arrays");
+      d.tri_count = m.numFaces;
+      out_tris.reserve(out_tris.size() + m.numFaces);
+      for (uint32_t f = 0; f < m.numFaces; ++f) {
+        const RefFace& fc = m.faces[f];
+        for (int k = 0; k < 3; ++k)
+          if (fc.v[k] >= m.numVerts || fc.n[k] >= m.numNorms)
+            return fail(TRC_ERR_INVALID, "object " + std::to_string(i) + ": face index out of range");
+        DevTri t;
+        memset(&t, 0, sizeof t);
+        // Mesh::getTriangle (Mesh.inl:56-62) + the edge vectors of Ray.inl:190-191
+        t.v0 = m.verts[fc.v[0]];
+        t.e1 = m.verts[fc.v[1]] - m.verts[fc.v[0]];
+        t.e2 = m.verts[fc.v[2]] - m.verts[fc.v[0]];
+        t.n0 = m.norms[fc.n[0]]; t.n1 = m.norms[fc.n[1]]; t.n2 = m.norms[fc.n[2]];
+        out_tris.push_back(t);
+      }
+    }
+    out_objs[i] = d;
+  }
+  return TRC_OK;
+}
+
+int begin_timing(trc_ctx* c) { HIP_TRY(hipEventRecord(c->ev_start, c->stream)); return TRC_OK; }
+int end_timing(trc_ctx* c) { HIP_TRY(hipEventRecord(c->ev_stop, c->stream)); c->timed = true; return TRC_OK; }
+
+} // namespace
+
+extern "C" {
+
+const char* trc_last_error_string(void) { return g_last_error.c_str(); }
+const char* trc_version(void) { return "tracer_amd 0.1 (gfx950)"; }
+
+int trc_create(int device, uint32_t width, uint32_t height, void* stream, trc_ctx** out) {
+  if (!out) return fail(TRC_ERR_INVALID, "trc_create: out is null");
+  *out = nullptr;
+  if (width == 0 || height == 0 || (uint64_t)width * height > 0x7FFFFFFFull)
+    return fail(TRC_ERR_INVALID, "trc_create: bad image size");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(TRC_ERR_INVALID, "trc_create: no such device");
+  HIP_TRY(hipSetDevice(device));
+  trc_ctx* c = new trc_ctx;
+  c->device = device; c->w = width; c->h = height; c->npix = width * height;
+  int rc = [&]() -> int {
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIP_TRY(hipEventCreate(&c->ev_start));
+    HIP_TRY(hipEventCreate(&c->ev_mid));
+    HIP_TRY(hipEventCreate(&c->ev_stop));
+    HIP_TRY(hipMalloc((void**)&c->film_own, sizeof(float) * 3ull * c->npix));
+    HIP_TRY(hipMalloc((void**)&c->ldr, sizeof(uint32_t) * c->npix));
+    HIP_TRY(hipMalloc((void**)&c->counters, sizeof(DeviceCounters)));
+    c->film = c->film_own;
+    HIP_TRY(hipMemsetAsync(c->film_own, 0, sizeof(float) * 3ull * c->npix, c->stream));
+    HIP_TRY(hipMemsetAsync(c->ldr, 0, sizeof(uint32_t) * c->npix, c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(DeviceCounters), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TRC_OK;
+  }();
+  if (rc != TRC_OK) { trc_destroy(c); return rc; }
+  *out = c;
+  return TRC_OK;
+}
+
+int trc_destroy(trc_ctx* c) {
+  if (!c) return TRC_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_dev(c->objs_d); free_dev(c->tris_d);
+  free_dev(c->film_own); free_dev(c->ldr);
+  free_dev(c->hit_id); free_dev(c->hit_t); free_dev(c->hit_pos); free_dev(c->hit_nor);
+  free_dev(c->state_mem[0]); free_dev(c->state_mem[1]); free_dev(c->queue_count);
+  free_dev(c->counters);
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+  if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return TRC_OK;
+}
+
+int trc_set_option(trc_ctx* c, int option, int value) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  switch (option) {
+    case TRC_OPT_RNG_MODE:
+      if (value != TRC_RNG_REFERENCE && value != TRC_RNG_DECORRELATED) return fail(TRC_ERR_INVALID, "bad rng mode");
+      c->rng_mode = value; return TRC_OK;
+    case TRC_OPT_PIPELINE:
+      if (value < TRC_PIPE_WAVEFRONT || value > TRC_PIPE_FUSED) return fail(TRC_ERR_INVALID, "bad pipeline");
+      c->pipeline = value; return TRC_OK;
+    case TRC_OPT_RECORD_HITS:
+      c->record_hits = value ? 1 : 0; return TRC_OK;
+    default: return fail(TRC_ERR_INVALID, "unknown option");
+  }
+}
+
+int trc_upload_scene(trc_ctx* c, const void* objects, uint32_t count) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  if (!objects || count == 0) return fail(TRC_ERR_INVALID, "trc_upload_scene: empty scene");
+  std::vector<DevObject> objs; std::vector<DevTri> tris;
+  int rc = flatten_scene((const RefObject*)objects, count, objs, tris);
+  if (rc != TRC_OK) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  free_dev(c->objs_d); free_dev(c->tris_d);
+  c->nobj = 0;
+  HIP_TRY(hipMalloc((void**)&c->objs_d, sizeof(DevObject) * objs.size()));
+  // always allocate one record so the kernels get a valid base pointer
+  HIP_TRY(hipMalloc((void**)&c->tris_d, sizeof(DevTri) * (tris.empty() ? 1 : tris.size())));
+  HIP_TRY(hipMemcpy(c->objs_d, objs.data(), sizeof(DevObject) * objs.size(), hipMemcpyHostToDevice));
+  if (!tris.empty())
+    HIP_TRY(hipMemcpy(c->tris_d, tris.data(), sizeof(DevTri) * tris.size(), hipMemcpyHostToDevice));
+  c->objs_h.swap(objs);
+  c->nobj = count;
+  return TRC_OK;
+}
+
+int trc_update_object(trc_ctx* c, uint32_t index, const float matrix[16], const float matrixi[16]) {
+  if (!c || !matrix || !matrixi) return fail(TRC_ERR_INVALID, "null argument");
+  if (c->nobj == 0) return fail(TRC_ERR_NO_SCENE, "no scene uploaded");
+  if (index >= c->nobj) return fail(TRC_ERR_INVALID, "trc_update_object: index out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  DevObject& d = c->objs_h[index];
+  affine_from_mat4(d.m, matrix);
+  affine_from_mat4(d.mi, matrixi);
+  // stream-ordered like the reference's cudaMemcpy on the default stream (Renderer.cpp:224)
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(c->objs_d + index, &d, sizeof(DevObject), hipMemcpyHostToDevice));
+  return TRC_OK;
+}
+
+int trc_raytrace1(trc_ctx* c, const trc_camera* cam) {
+  if (!c || !cam) return fail(TRC_ERR_INVALID, "null argument");
+  if (c->nobj == 0) return fail(TRC_ERR_NO_SCENE, "no scene uploaded");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->record_hits) { int rc = ensure_hit_buffers(c); if (rc) return rc; }
+  FrameParams fp = make_params(c, cam, 0);
+  int rc = begin_timing(c); if (rc) return rc;
+  if (c->record_hits) launch_raytrace1(fp, c->ldr, c->hit_id, c->hit_t, c->hit_pos, c->hit_nor, c->stream);
+  else launch_raytrace1(fp, c->ldr, nullptr, nullptr, nullptr, nullptr, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+  return end_timing(c);
+}
+
+int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
+                  uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters) {
+  if (!c || !cam) return fail(TRC_ERR_INVALID, "null argument");
+  if (c->nobj == 0) return fail(TRC_ERR_NO_SCENE, "no scene uploaded");
+  if (iter_first == 0) return fail(TRC_ERR_INVALID, "trc_pathtrace: iterations are 1-based");
+  if (n_iters == 0) return TRC_OK;
+  if (n_iters > 1 && iter_stride == 0) return fail(TRC_ERR_INVALID, "trc_pathtrace: zero stride");
+  if ((uint64_t)iter_first + (uint64_t)(n_iters - 1) * iter_stride > 0xFFFFFFFFull)
+    return fail(TRC_ERR_INVALID, "trc_pathtrace: iteration number overflows 32 bits");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameParams fp = make_params(c, cam, seed);
+  const uint32_t last_iter = iter_first + (n_iters - 1) * iter_stride;
+  if (c->pipeline != TRC_PIPE_FUSED) {
+    int rc = ensure_wavefront_state(c, c->pipeline == TRC_PIPE_COMPACTED); if (rc) return rc;
+  }
+  int rc = begin_timing(c); if (rc) return rc;
+  if (c->pipeline == TRC_PIPE_FUSED) {
+    launch_fused(fp, iter_first, iter_stride, n_iters, c->film, c->counters, c->stream);
+  } else {
+    const bool compact = c->pipeline == TRC_PIPE_COMPACTED;
+    for (uint32_t k = 0; k < n_iters; ++k)
+      launch_wavefront_iteration(fp, iter_first + k * iter_stride, compact, c->state[0],
+                                 compact ? c->state[1] : c->state[0], c->queue_count,
+                                 c->film, c->counters, c->stream);
+  }
+  HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+  launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
+  HIP_TRY(hipGetLastError());
+  return end_timing(c);
+}
+
+int trc_reset_film(trc_ctx* c) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->film, 0, sizeof(float) * 3ull * c->npix, c->stream));
+  return TRC_OK;
+}
+
+int trc_tonemap(trc_ctx* c, float iters) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  launch_tonemap(c->film, c->npix, iters, c->ldr, c->stream);
+  HIP_TRY(hipGetLastError());
+  return TRC_OK;
+}
+
+int trc_read_film(trc_ctx* c, float* rgb) {
+  if (!c || !rgb) return fail(TRC_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(rgb, c->film, sizeof(float) * 3ull * c->npix, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TRC_OK;
+}
+
+int trc_write_film(trc_ctx* c, const float* rgb) {
+  if (!c || !rgb) return fail(TRC_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->film, rgb, sizeof(float) * 3ull * c->npix, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TRC_OK;
+}
+
+int trc_read_ldr(trc_ctx* c, uint32_t* bgra) {
+  if (!c || !bgra) return fail(TRC_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(bgra, c->ldr, sizeof(uint32_t) * c->npix, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TRC_OK;
+}
+
+int trc_read_hits(trc_ctx* c, int32_t* ids, float* ts, float* pos3, float* nor3) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  if (!c->hit_id) return fail(TRC_ERR_INVALID, "trc_read_hits: no trc_raytrace1 with TRC_OPT_RECORD_HITS yet");
+  HIP_TRY(hipSetDevice(c->device));
+  if (ids) HIP_TRY(hipMemcpyAsync(ids, c->hit_id, sizeof(int32_t) * c->npix, hipMemcpyDeviceToHost, c->stream));
+  if (ts) HIP_TRY(hipMemcpyAsync(ts, c->hit_t, sizeof(float) * c->npix, hipMemcpyDeviceToHost, c->stream));
+  if (pos3) HIP_TRY(hipMemcpyAsync(pos3, c->hit_pos, sizeof(float) * 3ull * c->npix, hipMemcpyDeviceToHost, c->stream));
+  if (nor3) HIP_TRY(hipMemcpyAsync(nor3, c->hit_nor, sizeof(float) * 3ull * c->npix, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TRC_OK;
+}
+
+int trc_synchronize(trc_ctx* c) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TRC_OK;
+}
+
+int trc_film_device_ptr(trc_ctx* c, void** dev_ptr) {
+  if (!c || !dev_ptr) return fail(TRC_ERR_INVALID, "null argument");
+  *dev_ptr = c->film;
+  return TRC_OK;
+}
+
+int trc_bind_film(trc_ctx* c, void* dev_ptr) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  if (dev_ptr && ((uintptr_t)dev_ptr & 15)) return fail(TRC_ERR_INVALID, "trc_bind_film: pointer not 16-byte aligned");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->film = dev_ptr ? (float*)dev_ptr : c->film_own;
+  return TRC_OK;
+}
+
+int trc_get_counters(trc_ctx* c, trc_counters* out) {
+  if (!c || !out) return fail(TRC_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  DeviceCounters h;
+  HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  out->live_segments = h.live_segments; out->paths = h.paths; out->tri_tests = h.tri_tests;
+  return TRC_OK;
+}
+
+int trc_reset_counters(trc_ctx* c) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(DeviceCounters), c->stream));
+  return TRC_OK;
+}
+
+int trc_last_render_ms(trc_ctx* c, float* ms) {
+  if (!c || !ms) return fail(TRC_ERR_INVALID, "null argument");
+  if (!c->timed) return fail(TRC_ERR_INVALID, "trc_last_render_ms: nothing rendered yet");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(c->ev_stop));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+  return TRC_OK;
+}
+
+int trc_last_kernel_ms(trc_ctx* c, float* ms) {
+  if (!c || !ms) return fail(TRC_ERR_INVALID, "null argument");
+  if (!c->timed) return fail(TRC_ERR_INVALID, "trc_last_kernel_ms: nothing rendered yet");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(c->ev_mid));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_mid));
+  return TRC_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// The reference's own launcher signatures (raytrace.cu:189-238), for a Renderer.cpp that keeps
+// its device-side bookkeeping unchanged. `scene_d` is the device copy of Object[] that
+// Renderer::initScene built (Renderer.cpp:112-151): Object records whose m_mesh points at a
+// device Mesh whose m_verts/m_norms/m_faces point at device arrays. Each call reads the small
+// Object array back (168 B per object) so that Renderer::updateScene's in-place matrix edits
+// (Renderer.cpp:221-225) are honoured; meshes are immutable in the reference and are read back
+// and flattened once per device Mesh pointer.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct LegacyMesh {
+  RefMesh host;                 // host copy with host pointers
+  std::vector<f3> verts, norms;
+  std::vector<RefFace> faces;
+};
+
+struct LegacyScene {
+  std::vector<const void*> mesh_keys;   // device Mesh pointers the triangle stream was built from
+  DevObject* objs_d = nullptr; uint32_t objs_cap = 0;
+  DevTri* tris_d = nullptr;
+  DeviceCounters* counters = nullptr;
+};
+
+std::mutex g_legacy_mutex;
+std::unordered_map<const void*, LegacyMesh*> g_legacy_meshes;   // key: device Mesh*
+std::unordered_map<const void*, LegacyScene*> g_legacy_scenes;  // key: scene_d
+
+int legacy_prepare(const void* scene_d, uint32_t sceneSize, LegacyScene** out) {
+  if (!scene_d || sceneSize == 0) return fail(TRC_ERR_INVALID, "legacy launcher: empty scene");
+  std::vector<RefObject> objs(sceneSize);
+  HIP_TRY(hipMemcpy(objs.data(), scene_d, sizeof(RefObject) * sceneSize, hipMemcpyDeviceToHost));
+  std::vector<const void*> keys(sceneSize);
+  for (uint32_t i = 0; i < sceneSize; ++i) {
+    const void* key = objs[i].mesh;
+    keys[i] = key;
+    if (!key) return fail(TRC_ERR_INVALID, "legacy launcher: null m_mesh");
+    auto it = g_legacy_meshes.find(key);
+    if (it == g_legacy_meshes.end()) {
+      LegacyMesh* lm = new LegacyMesh;
+      HIP_TRY(hipMemcpy(&lm->host, key, sizeof(RefMesh), hipMemcpyDeviceToHost));
+      RefMesh& m = lm->host;
+      if (m.type == REF_MESH) {
+        lm->verts.resize(m.numVerts); lm->norms.resize(m.numNorms); lm->faces.resize(m.numFaces);
+        if (m.numVerts) HIP_TRY(hipMemcpy(lm->verts.data(), m.verts, sizeof(f3) * m.numVerts, hipMemcpyDeviceToHost));
+        if (m.numNorms) HIP_TRY(hipMemcpy(lm->norms.data(), m.norms, sizeof(f3) * m.numNorms, hipMemcpyDeviceToHost));
+        if (m.numFaces) HIP_TRY(hipMemcpy(lm->faces.data(), m.faces, sizeof(RefFace) * m.numFaces, hipMemcpyDeviceToHost));
+      }
+      m.verts = lm->verts.data(); m.norms = lm->norms.data(); m.faces = lm->faces.data();
+      it = g_legacy_meshes.emplace(key, lm).first;
+    }
+    objs[i].mesh = &it->second->host;
+  }
+  LegacyScene*& ls = g_legacy_scenes[scene_d];
+  if (!ls) ls = new LegacyScene;
+  std::vector<DevObject> dobjs; std::vector<DevTri> dtris;
+  int rc = flatten_scene(objs.data(), sceneSize, dobjs, dtris);
+  if (rc) return rc;
+  if (ls->objs_cap < sceneSize) {
+    free_dev(ls->objs_d);
+    HIP_TRY(hipMalloc((void**)&ls->objs_d, sizeof(DevObject) * sceneSize));
+    ls->objs_cap = sceneSize;
+  }
+  HIP_TRY(hipMemcpy(ls->objs_d, dobjs.data(), sizeof(DevObject) * sceneSize, hipMemcpyHostToDevice));
+  if (ls->mesh_keys != keys || !ls->tris_d) {
+    free_dev(ls->tris_d);
+    HIP_TRY(hipMalloc((void**)&ls->tris_d, sizeof(DevTri) * (dtris.empty() ? 1 : dtris.size())));
+    if (!dtris.empty())
+      HIP_TRY(hipMemcpy(ls->tris_d, dtris.data(), sizeof(DevTri) * dtris.size(), hipMemcpyHostToDevice));
+    ls->mesh_keys = keys;
+  }
+  if (!ls->counters) {
+    HIP_TRY(hipMalloc((void**)&ls->counters, sizeof(DeviceCounters)));
+    HIP_TRY(hipMemset(ls->counters, 0, sizeof(DeviceCounters)));
+  }
+  *out = ls;
+  return TRC_OK;
+}
+
+FrameParams legacy_params(uint32_t w, uint32_t h, const float* campos, const float* A, const float* B,
+                          const float* Cc, float lensRadius, float focalDist, const LegacyScene* ls,
+                          uint32_t nobj, uint64_t seed) {
+  FrameParams fp;
+  fp.w = w; fp.h = h; fp.npix = w * h;
+  fp.campos = ld3(campos); fp.A = ld3(A); fp.B = ld3(B); fp.C = ld3(Cc);
+  fp.nA = normalize(fp.A); fp.nB = normalize(fp.B);
+  fp.lensRadius = lensRadius; fp.focalDist = focalDist;
+  fp.objs = ls->objs_d; fp.tris = ls->tris_d; fp.nobj = nobj;
+  fp.seed_lo = (uint32_t)seed; fp.seed_hi = (uint32_t)(seed >> 32);
+  fp.rng_mode = TRC_RNG_REFERENCE;
+  return fp;
+}
+
+} // namespace
+
+extern "C" {
+
+void raytrace1(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
+               const float* campos, const float* A, const float* B, const float* C,
+               const void* scene_d, uint32_t sceneSize) {
+  (void)time;
+  std::lock_guard<std::mutex> lock(g_legacy_mutex);
+  LegacyScene* ls = nullptr;
+  if (!pbo_out || !campos || !A || !B || !C || w == 0 || h == 0 ||
+      legacy_prepare(scene_d, sceneSize, &ls) != TRC_OK) {
+    fprintf(stderr, "tracer_amd: raytrace1: %s\n", g_last_error.empty() ? "bad argument" : g_last_error.c_str());
+    return;
+  }
+  FrameParams fp = legacy_params(w, h, campos, A, B, C, 0.0f, 0.0f, ls, sceneSize, 0);
+  launch_raytrace1(fp, pbo_out, nullptr, nullptr, nullptr, nullptr, nullptr);   // default stream, as the reference
+}
+
+void pathtrace(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
+               const float* campos, const float* A, const float* B, const float* C,
+               float lensRadius, float focalDist,
+               const void* scene_d, uint32_t sceneSize,
+               void* rand_d, void* rays_d, void* col_d, int* idx_d,
+               void* film_d, uint32_t filmIters) {
+  (void)rand_d; (void)rays_d; (void)col_d; (void)idx_d;   // ray state lives in registers
+  std::lock_guard<std::mutex> lock(g_legacy_mutex);
+  LegacyScene* ls = nullptr;
+  if (!pbo_out || !film_d || !campos || !A || !B || !C || w == 0 || h == 0 || filmIters == 0 ||
+      legacy_prepare(scene_d, sceneSize, &ls) != TRC_OK) {
+    fprintf(stderr, "tracer_amd: pathtrace: %s\n", g_last_error.empty() ? "bad argument" : g_last_error.c_str());
+    return;
+  }
+  const uint64_t seed = (uint64_t)(time * 100.0f);        // raytrace.cu:205
+  FrameParams fp = legacy_params(w, h, campos, A, B, C, lensRadius, focalDist, ls, sceneSize, seed);
+  launch_fused(fp, filmIters, 1, 1, (float*)film_d, ls->counters, nullptr);
+  launch_tonemap((const float*)film_d, fp.npix, (float)filmIters, pbo_out, nullptr);
+}
+
+} // extern "C"
