@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the per-bounce path-tracing loop on MI355X.
+
+Metric (BASELINE.json): Mpath-segments/s, Cornell box 512x512 path trace (mode 2), 300
+iterations. A path segment is one closest-hit evaluation for a live path inside one bounce
+pass (reference src/raytrace.cu:119-127); segments are counted on the device.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one full 300-iteration render of the 512x512 Cornell box per GPU, inputs (scene,
+camera) resident on the device. For N > 1 (launched by torch.distributed.run, one rank per
+GPU) rank r renders iterations r+1, r+1+N, ... (300 of them: sample-index partition, weak
+scaling) and every step ends with ONE sum-reduce of the film buffers to rank 0 over RCCL,
+followed by the display transform on rank 0 -- the only exchange the path has.
+
+Rank 0 prints one JSON line. Only the `cpu_baseline` leg touches oracle/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+W = H = 512
+ITERS = 300
+SEED = 1
+
+# algorithmic FP32 flop of the reference's arithmetic on the default Cornell
+# scene (9 object tests / segment, brute-force 20-triangle mesh behind an AABB).
+FLOP_PER_SEGMENT = 880.0
+FLOP_PER_PATH = 118.0          # ray generation (~103) + accumulate (~15)
+BYTES_PER_SEGMENT_REF = 108.0  # reference buffer layout, SURVEY.md 8(d)
+PEAK_FP32_TFLOPS = 157.3       # MI355X FP32 vector peak (packed FMA), MI355X_MICROARCH.md
+PEAK_FP32_UNFUSED_TFLOPS = 39.3  # one unfused, unpacked add/mul per lane per clock
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline():
+    """Time the CPU oracle (plain-C restatement, bit-identical to the reference host build)
+    on this box's host cores over a bounded sample of the same workload."""
+    from oracle.pyoracle import Oracle, available
+    o = Oracle("c")
+    o.set_math_mode(Oracle.MATH_LIBM)
+    s = o.scene_create(0)
+    cam = o.camera_default(W, H)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    out = {}
+    # single thread: 8 iterations of the 512x512 workload
+    t = time.perf_counter()
+    r = o.pathtrace(s, W, H, cam, SEED, 1, 8, want_pbo=False, nthreads=1)
+    dt1 = time.perf_counter() - t
+    v1 = r["stats"]["live_segments"] / dt1 / 1e6
+    # all threads: 48 iterations
+    n_mt = 48
+    t = time.perf_counter()
+    r = o.pathtrace(s, W, H, cam, SEED, 1, n_mt, want_pbo=False, nthreads=threads)
+    dtm = time.perf_counter() - t
+    vm = r["stats"]["live_segments"] / dtm / 1e6
+    out = {"value": round(vm, 3), "unit": "Mseg/s", "cores": threads, "kind": "port",
+           "sample": f"cornell {W}x{H} mode 2, {n_mt} of {ITERS} iterations, OpenMP over pixels "
+                     f"({threads} threads); single thread: 8 iterations",
+           "single_thread_value": round(v1, 3)}
+    if available("ref"):
+        # the reference's own .inl + GLM host build (single-threaded by construction)
+        R = Oracle("ref")
+        sr = R.scene_create(0, data_dir=os.path.join(HERE, "tracer_amd", "data"))
+        t = time.perf_counter()
+        rr = R.pathtrace(sr, W, H, cam, SEED, 1, 8, want_pbo=False)
+        dtr = time.perf_counter() - t
+        out["reference_host_build_single_thread_value"] = round(rr["stats"]["live_segments"] / dtr / 1e6, 3)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pipeline", type=int, default=2, help="0 wavefront, 1 compacted, 2 fused (default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import tracer_amd as ta
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # scene + camera through the product's own host API (no oracle here)
+    scene = ta.Scene(0)
+    cam = ta.camera_default(W, H)
+    stream = torch.cuda.current_stream().cuda_stream
+    tr = ta.Tracer(W, H, device=local_rank, stream=stream)
+    tr.set_pipeline(args.pipeline)
+    tr.upload_scene(scene.objects_ptr, scene.size)
+    film = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)   # torch owns the film so RCCL can reduce it
+    tr.bind_film(film.data_ptr())
+
+    def step():
+        film.zero_()
+        # rank r renders iterations r+1, r+1+world, ...  (ITERS of them)
+        tr.pathtrace(cam, SEED, rank + 1, ITERS, iter_stride=world)
+        if world > 1:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                tr.tonemap(ITERS * world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    tr.reset_counters()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP events recorded on the launch stream around the path kernels of this step
+        # (read after the fence below would only see the last step, so query per step; the
+        # query waits for the kernel, which the next step's film.zero_() would do anyway)
+        kernel_ms.append(tr.last_kernel_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    cnt = tr.counters()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        seg = torch.tensor([cnt["live_segments"], cnt["paths"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+        total_segments, total_paths = float(seg[0].item()), float(seg[1].item())
+    else:
+        total_segments, total_paths = float(cnt["live_segments"]), float(cnt["paths"])
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_segments / elapsed / 1e6
+        # roofline of the dominant kernel (rank 0's launches): algorithmic flop / measured duration
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        seg_per_launch = cnt["live_segments"] / args.steps
+        paths_per_launch = cnt["paths"] / args.steps
+        flop = seg_per_launch * FLOP_PER_SEGMENT + paths_per_launch * FLOP_PER_PATH
+        achieved = flop / (k_ms * 1e-3) / 1e12
+        kernel_name = {0: "k_bounce<false> (+k_raygen)", 1: "k_bounce<true> (+k_raygen)", 2: "k_fused"}[args.pipeline]
+        out = {
+            "metric": "Mpath-segments/s, Cornell box 512x512 path trace (mode 2), 300 iterations",
+            "value": round(value, 2),
+            "unit": "Mseg/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cornell_box_512x512_mode2_300it", "width": W, "height": H,
+                       "iterations_per_gpu": ITERS, "path_depth": 5, "rng": "philox4x32-10, reference reuse",
+                       "pipeline": ["wavefront", "compacted", "fused"][args.pipeline],
+                       "parallelism": f"sample-index x{world}, one RCCL film sum-reduce per step" if world > 1 else "single GPU",
+                       "live_segments_per_step_per_gpu": int(seg_per_launch),
+                       "segments_per_path": round(seg_per_launch / max(paths_per_launch, 1), 4)},
+            "roofline": {
+                "bound": "valu",
+                "kernel": kernel_name,
+                "achieved": round(achieved, 3),
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS,
+                "frac_unfused": round(achieved / PEAK_FP32_UNFUSED_TFLOPS, 4),
+                "kernel_ms": round(k_ms, 4),
+                "flop_per_segment": FLOP_PER_SEGMENT,
+                "flop_per_path": FLOP_PER_PATH,
+                "traffic": None,
+                "hbm_algorithmic_GBs": round(seg_per_launch * BYTES_PER_SEGMENT_REF / (k_ms * 1e-3) / 1e9, 2),
+                "hbm_peak_GBs": PEAK_HBM_GBS,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+
+    tr.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

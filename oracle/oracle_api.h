@@ -107,6 +107,11 @@ void  orc_rand3_api(uint64_t seed, uint32_t index, uint32_t iter, uint32_t dim, 
 void  orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t orc_rgb_to_int(float r, float g, float b);
 
+/* portable-math unit entry points (oracle/pmath.h); C restatement only */
+void  orc_pm_sincos(float x, float* s, float* c);
+float orc_pm_acos(float x);
+float orc_pm_pow(float x, float y);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,10 @@ class Oracle:
         L.orc_rand3_api.argtypes = [u64, u32, u32, u32, vp]
         L.orc_philox.argtypes = [vp, vp, vp]
         L.orc_rgb_to_int.argtypes = [f32, f32, f32]; L.orc_rgb_to_int.restype = u32
+        if kind == "c":
+            L.orc_pm_sincos.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
+            L.orc_pm_acos.argtypes = [f32]; L.orc_pm_acos.restype = f32
+            L.orc_pm_pow.argtypes = [f32, f32]; L.orc_pm_pow.restype = f32
 
     # -- configuration -------------------------------------------------------------
     def name(self):
@@ -219,3 +223,15 @@ class Oracle:
 
     def rgb_to_int(self, r, g, b):
         return int(self.lib.orc_rgb_to_int(r, g, b))
+
+    # -- portable math (C restatement only) ---------------------------------------------
+    def pm_sincos(self, x):
+        s = C.c_float(); c = C.c_float()
+        self.lib.orc_pm_sincos(x, C.byref(s), C.byref(c))
+        return np.float32(s.value), np.float32(c.value)
+
+    def pm_acos(self, x):
+        return np.float32(self.lib.orc_pm_acos(x))
+
+    def pm_pow(self, x, y):
+        return np.float32(self.lib.orc_pm_pow(x, y))

@@ -820,3 +820,7 @@ void orc_rand_point_disk(float r1, float r2, float r3, float out[2]) { v2 o = ra
 void orc_rand3_api(uint64_t seed, uint32_t index, uint32_t iter, uint32_t dim, float out[3]) { orc_rand3(seed, index, iter, dim, out); }
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32_10(ctr, key, out); }
 uint32_t orc_rgb_to_int(float r, float g, float b) { return rgbToInt(V3(r, g, b)); }
+
+void orc_pm_sincos(float x, float* s, float* c) { pm_sincosf(x, s, c); }
+float orc_pm_acos(float x) { return pm_acosf(x); }
+float orc_pm_pow(float x, float y) { return pm_powf(x, y); }

@@ -1,0 +1,139 @@
+"""The two other faces of the boundary, on a real GPU:
+  * the reference's own launcher signatures `pathtrace` / `raytrace1` (raytrace.cu:189-238)
+    fed with device buffers laid out exactly as the reference's Renderer.cpp builds them;
+  * the C++ host mirror (Renderer / Camera / Object / Mesh classes) driven by a headless
+    analogue of the reference's main.cpp (tests/cpp/headless_main.cpp)."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import tracer_amd
+    tracer_amd.load_library()
+    return tracer_amd
+
+
+def _device_scene(torch, raw, n):
+    """Deep-copy Object[] to the device as Renderer::initScene does (Renderer.cpp:112-151)."""
+    keep = []
+    objs = bytearray(raw)
+    for i in range(n):
+        meshp = struct.unpack("Q", raw[168 * i + 128:168 * i + 136])[0]
+        mesh = bytearray(C.string_at(meshp, 72))
+        nv, nn, nf = struct.unpack("III", mesh[0:12]); pv, pn, pf = struct.unpack("QQQ", mesh[16:40])
+        ptrs = []
+        for p, nbytes in ((pv, 12 * nv), (pn, 12 * nn), (pf, 24 * nf)):
+            if nbytes:
+                t = torch.frombuffer(bytearray(C.string_at(p, nbytes)), dtype=torch.uint8).cuda()
+                keep.append(t); ptrs.append(t.data_ptr())
+            else:
+                ptrs.append(0)
+        mesh[16:40] = struct.pack("QQQ", *ptrs)
+        mt = torch.frombuffer(mesh, dtype=torch.uint8).cuda(); keep.append(mt)
+        objs[168 * i + 128:168 * i + 136] = struct.pack("Q", mt.data_ptr())
+    sd = torch.frombuffer(objs, dtype=torch.uint8).cuda(); keep.append(sd)
+    return sd, keep
+
+
+def test_reference_launcher_signatures(ta, oracle_c):
+    import torch
+    from oracle.pyoracle import Oracle
+    L = ta.load_library()
+    w, h = 96, 64
+    n = w * h
+    sc = ta.Scene(0)
+    scene_d, keep = _device_scene(torch, sc.raw_objects(), sc.size)
+    cam = ta.camera_default(w, h)
+    f3 = C.c_float * 3
+    args_cam = [f3(*cam.campos), f3(*cam.A), f3(*cam.B), f3(*cam.C)]
+    pbo = torch.zeros(n, dtype=torch.int32, device="cuda")
+    vp = C.c_void_p
+    L.raytrace1.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float, f3, f3, f3, f3, vp, C.c_uint32]
+    L.raytrace1.restype = None
+    L.pathtrace.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float, f3, f3, f3, f3, C.c_float, C.c_float,
+                            vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32]
+    L.pathtrace.restype = None
+    L.raytrace1(pbo.data_ptr(), w, h, 0.01, *args_cam, scene_d.data_ptr(), sc.size)
+    torch.cuda.synchronize()
+    s = oracle_c.scene_create(0)
+    ocam = oracle_c.camera_default(w, h)
+    ref = oracle_c.raytrace1(s, w, h, ocam)
+    assert np.array_equal(pbo.cpu().numpy().view(np.uint32), ref["pbo"])
+
+    # mode 2 exactly as Renderer::render drives it: ++filmIters, time += DELTA_T per frame
+    rays = torch.zeros(n * 6, dtype=torch.float32, device="cuda"); col = torch.zeros(n * 3, dtype=torch.float32, device="cuda")
+    rnd = torch.zeros(n * 3, dtype=torch.float32, device="cuda"); idx = torch.zeros(n, dtype=torch.int32, device="cuda")
+    film = torch.full((n * 3,), 5.0, dtype=torch.float32, device="cuda")      # garbage: iteration 1 must zero it
+    oracle_c.set_math_mode(Oracle.MATH_PORTABLE)
+    try:
+        ref_film = np.zeros((n, 3), np.float32)
+        timer = np.float32(0.0)
+        for it in (1, 2, 3):
+            timer = np.float32(timer + np.float32(0.01))
+            L.pathtrace(pbo.data_ptr(), w, h, float(timer), *args_cam, cam.lensRadius, cam.focalDist,
+                        scene_d.data_ptr(), sc.size, rnd.data_ptr(), rays.data_ptr(), col.data_ptr(), idx.data_ptr(),
+                        film.data_ptr(), it)
+            seed = int(np.uint64(np.float32(timer * np.float32(100.0))))
+            r = oracle_c.pathtrace(s, w, h, ocam, seed, it, 1, film=ref_film)
+            ref_film = r["film"]
+        torch.cuda.synchronize()
+        assert film.cpu().numpy().tobytes() == ref_film.tobytes()
+        assert np.array_equal(pbo.cpu().numpy().view(np.uint32), r["pbo"])
+        # Renderer::updateScene edits scene_d in place (Renderer.cpp:221-225): must be honoured
+        oracle_c.scene_translate(s, 6, [0.0, 1.0, 0.0])
+        d = oracle_c.scene_object(s, 6, with_mesh=False)
+        upd = torch.from_numpy(np.concatenate([d["matrix"], d["matrixi"]])).cuda()
+        scene_d[168 * 6:168 * 6 + 128] = upd.view(torch.uint8)
+        L.raytrace1(pbo.data_ptr(), w, h, 0.0, *args_cam, scene_d.data_ptr(), sc.size)
+        torch.cuda.synchronize()
+        assert np.array_equal(pbo.cpu().numpy().view(np.uint32), oracle_c.raytrace1(s, w, h, ocam)["pbo"])
+    finally:
+        oracle_c.set_math_mode(Oracle.MATH_LIBM)
+
+
+def test_cpp_renderer_mirror(ta, tmp_path):
+    """headless_main drives Renderer::render(camera, timer) frame by frame like main.cpp:125-131;
+    the film must equal the same iterations issued through the C ABI."""
+    exe = os.path.join(REPO, "tests", "cpp", "bin", "headless_main")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(REPO, "tests", "cpp")], check=True)
+    data = os.path.join(REPO, "tracer_amd", "data")
+    w, h, frames = 80, 60, 5
+    out = str(tmp_path / "frame")
+    r = subprocess.run([exe, data, str(w), str(h), str(frames), out, "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert f"iterations {frames}" in r.stdout
+    film = np.fromfile(out + ".film", np.float32).reshape(-1, 3)
+    ldr = np.fromfile(out + ".ldr", np.uint32)
+    sc = ta.Scene(0)
+    tr = ta.Tracer(w, h)
+    tr.upload_scene(sc.objects_ptr, sc.size)
+    cam = ta.camera_default(w, h)
+    timer = np.float32(0.0)
+    for it in range(1, frames + 1):
+        timer = np.float32(timer + np.float32(0.01))
+        tr.pathtrace(cam, int(np.uint64(np.float32(timer * np.float32(100.0)))), it, 1)
+    assert tr.read_film().tobytes() == film.tobytes()
+    assert np.array_equal(tr.read_ldr(), ldr)
+    assert os.path.getsize(out + ".ppm") == len(f"P6\n{w} {h}\n255\n") + 3 * w * h
+    # mode 1 through the class, and the batched extension
+    r = subprocess.run([exe, data, str(w), str(h), "1", out + "1", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    tr.raytrace1(cam)
+    assert np.array_equal(tr.read_ldr(), np.fromfile(out + "1.ldr", np.uint32))
+    r = subprocess.run([exe, data, str(w), str(h), "4", out + "b", "2", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    tr.reset_film()
+    tr.pathtrace(cam, 1, 1, 4)            # time = 0.01 -> seed (uint64)(0.01f*100) = 1
+    assert tr.read_film().tobytes() == np.fromfile(out + "b.film", np.float32).tobytes()
+    tr.close()

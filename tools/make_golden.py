@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""tools/make_golden.py -- regenerate tests/golden/*.npz from the REFERENCE-LINKED oracle
+(oracle/_ref/libtracer_ref.so: the reference's own Ray/Object/Material/Mesh/Utils .inl +
+Camera.cpp + vendored GLM compiled with g++, see oracle/Makefile).
+
+Runs only where /root/reference exists (this build container). The fixtures are data --
+inputs and expected outputs -- and are what pins the plain-C oracle and the HIP path on
+machines that do not have the reference (the GPU box).
+
+    make -C oracle && python tools/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from oracle.pyoracle import Oracle  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def scene_arrays(o, s, prefix):
+    d = {}
+    n = o.scene_size(s)
+    d[prefix + "n"] = np.array([n], np.int32)
+    for i in range(n):
+        ob = o.scene_object(s, i)
+        for k, v in ob.items():
+            d[f"{prefix}{i}_{k}"] = np.asarray(v)
+    return d
+
+
+def main():
+    R = Oracle("ref")
+    assert R.name() == "reference-host-build"
+    os.makedirs(OUT, exist_ok=True)
+    meta = {"generator": "tools/make_golden.py", "oracle": R.name(),
+            "flags": "g++ -std=c++14 -O2 -ffp-contract=off -DNDEBUG", "hashes": {}}
+
+    # ---- scenes and cameras -------------------------------------------------------------
+    scenes = {}
+    d = {}
+    for variant, param in ((0, 0), (1, 0), (2, 1)):
+        s = R.scene_create(variant, param)
+        scenes[(variant, param)] = s
+        d.update(scene_arrays(R, s, f"v{variant}p{param}_"))
+    cams = [(512, 512, 0.0, 0.0), (256, 256, 0.0, 0.0), (3840, 2160, 0.0, 0.0), (512, 512, 0.3, -0.2),
+            (640, 480, -1.1, 0.4), (128, 96, 2.5, 1.0)]
+    d["camera_args"] = np.array(cams, np.float64)
+    d["cameras"] = np.stack([R.camera_default(int(a), int(b), c, e).as_array() for a, b, c, e in cams])
+    np.savez_compressed(os.path.join(OUT, "scenes.npz"), **d)
+
+    # ---- mode 1 (BASELINE.json configs[0]: 256x256 default scene) ---------------------------
+    s0 = scenes[(0, 0)]
+    cam = R.camera_default(256, 256)
+    r = R.raytrace1(s0, 256, 256, cam)
+    ids, cnt = np.unique(r["ids"], return_counts=True)
+    meta["mode1_256_id_histogram"] = {int(i): int(c) for i, c in zip(ids, cnt)}
+    meta["hashes"]["mode1_256_pos"] = sha(r["pos"]); meta["hashes"]["mode1_256_nor"] = sha(r["nor"])
+    np.savez_compressed(os.path.join(OUT, "mode1_256.npz"), cam=cam.as_array(), ids=r["ids"].astype(np.int8),
+                        ts=r["ts"], pbo=r["pbo"])
+    # other shapes / scenes, smaller
+    d = {}
+    cases = [("v0_96x64_rot", (0, 0), 96, 64, (96, 64, 0.3, -0.2)),
+             ("v1_64x64", (1, 0), 64, 64, (64, 64, 0.0, 0.0)),
+             ("v2_64x64", (2, 1), 64, 64, (64, 64, 0.0, 0.0)),
+             ("v0_33x17", (0, 0), 33, 17, (33, 17, -0.7, 0.1))]
+    for name, key, w, h, cargs in cases:
+        c = R.camera_default(*cargs)
+        rr = R.raytrace1(scenes[key], w, h, c)
+        d[name + "_cam"] = c.as_array(); d[name + "_ids"] = rr["ids"].astype(np.int8); d[name + "_ts"] = rr["ts"]
+        d[name + "_pbo"] = rr["pbo"]; d[name + "_pos"] = rr["pos"]; d[name + "_nor"] = rr["nor"]
+        d[name + "_shape"] = np.array([w, h, key[0], key[1]], np.int32)
+    np.savez_compressed(os.path.join(OUT, "mode1_small.npz"), **d)
+
+    # ---- mode 2: per-sample radiance and short accumulations ---------------------------------
+    d = {}
+    cases = [("v0_64x64", (0, 0), 64, 64, (64, 64, 0.0, 0.0), 11),
+             ("v1_64x48_rot", (1, 0), 64, 48, (64, 48, 0.3, -0.2), 12),
+             ("v0_33x17", (0, 0), 33, 17, (33, 17, -0.7, 0.1), 13)]
+    for name, key, w, h, cargs, seed in cases:
+        c = R.camera_default(*cargs)
+        d[name + "_cam"] = c.as_array()
+        d[name + "_shape"] = np.array([w, h, key[0], key[1], seed], np.int32)
+        for rng in (0, 1):
+            # single samples: iteration 1 and iteration 7 on a zero film
+            for it in (1, 7):
+                rr = R.pathtrace(scenes[key], w, h, c, seed, it, 1, rng_mode=rng)
+                d[f"{name}_rng{rng}_sample{it}"] = rr["film"]
+            rr = R.pathtrace(scenes[key], w, h, c, seed, 1, 6, rng_mode=rng)
+            d[f"{name}_rng{rng}_film6"] = rr["film"]; d[f"{name}_rng{rng}_pbo6"] = rr["pbo"]
+            d[f"{name}_rng{rng}_stats6"] = np.array([rr["stats"][k] for k in
+                                                     ("live_segments", "miss", "light", "depthcap", "diff", "trans", "mirr", "paths")], np.int64)
+            # strided subset (rank 1 of 2): iterations 2, 4, 6
+            rr = R.pathtrace(scenes[key], w, h, c, seed, 2, 3, iter_stride=2, rng_mode=rng)
+            d[f"{name}_rng{rng}_film_2_4_6"] = rr["film"]
+    np.savez_compressed(os.path.join(OUT, "mode2_small.npz"), **d)
+    # 512x512 headline config: iteration-1 sample hash + statistics of 4 iterations
+    c512 = R.camera_default(512, 512)
+    rr = R.pathtrace(s0, 512, 512, c512, 1, 1, 4)
+    meta["mode2_512_seed1_4it_stats"] = rr["stats"]
+    meta["hashes"]["mode2_512_seed1_film4"] = sha(rr["film"])
+    meta["mode2_512_seed1_film4_mean"] = [float(x) for x in (rr["film"].mean(0) / 4)]
+
+    # ---- unit-level known answers ---------------------------------
+    rs = np.random.RandomState(1234)
+    d = {}
+    nray = 400
+    org = rs.uniform(-4.5, 4.5, (nray, 3)).astype(np.float32)
+    org[: nray // 2] = np.array([0, 0, 13], np.float32)          # half from the camera
+    tgt = rs.uniform(-5, 5, (nray, 3)).astype(np.float32)
+    dirs = tgt - org
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([org, dirs], 1).astype(np.float32)
+    d["rays"] = rays
+    for key, s in (("v0", s0), ("v1", scenes[(1, 0)])):
+        t_all = np.zeros((nray, 9), np.float32); pos_all = np.zeros((nray, 9, 3), np.float32); nor_all = np.zeros((nray, 9, 3), np.float32)
+        st = np.zeros(nray, np.float32); sid = np.zeros(nray, np.int32); sp = np.zeros((nray, 3), np.float32); sn = np.zeros((nray, 3), np.float32)
+        for i in range(nray):
+            for ob in range(9):
+                t_all[i, ob], pos_all[i, ob], nor_all[i, ob] = R.intersect_object(s, ob, rays[i])
+            st[i], sid[i], sp[i], sn[i] = R.intersect_scene(s, rays[i])
+        d[key + "_obj_t"] = t_all; d[key + "_obj_pos"] = pos_all; d[key + "_obj_nor"] = nor_all
+        d[key + "_scene_t"] = st; d[key + "_scene_id"] = sid; d[key + "_scene_pos"] = sp; d[key + "_scene_nor"] = sn
+    nb = 300
+    rd = rs.normal(size=(nb, 3)); rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    nor = rs.normal(size=(nb, 3)); nor = (nor / np.linalg.norm(nor, axis=1, keepdims=True)).astype(np.float32)
+    rnd = rs.uniform(0, 1, (nb, 3)).astype(np.float32)
+    d["b_rd"] = rd; d["b_nor"] = nor; d["b_rnd"] = rnd
+    for mt, ior in ((0, 1.0), (1, 1.6), (1, 1.2), (2, 1.0)):
+        d[f"bounce_{mt}_{ior}"] = np.stack([R.bounce(mt, ior, rd[i], nor[i], rnd[i]) for i in range(nb)])
+    d["reflectance_1_1.6"] = np.array([R.reflectance(rd[i], nor[i], 1.0, 1.6) for i in range(nb)], np.float32)
+    d["reflectance_1.6_1"] = np.array([R.reflectance(rd[i], nor[i], 1.6, 1.0) for i in range(nb)], np.float32)
+    d["rand_vector"] = np.stack([R.rand_vector(float(rnd[i, 0]), float(rnd[i, 1])) for i in range(nb)])
+    d["rand_point_disk"] = np.stack([R.rand_point_disk(*[float(x) for x in rnd[i]]) for i in range(nb)])
+    d["rand_vector_hem"] = np.stack([R.rand_vector_hem(float(rnd[i, 0]), float(rnd[i, 1]), nor[i]) for i in range(nb)])
+    cols = np.concatenate([rs.uniform(-0.2, 1.2, (200, 3)), [[0, 0, 0], [1, 1, 1], [0.5, 0.25, 0.999999], [1 - 2 ** -24, 2 ** -24, 0.1]]]).astype(np.float32)
+    d["rgb_in"] = cols
+    d["rgb_out"] = np.array([R.rgb_to_int(*[float(x) for x in c]) for c in cols], np.uint32)
+    films = rs.uniform(0, 20, (200, 3)).astype(np.float32)
+    d["tonemap_film"] = films; d["tonemap_iters"] = np.array([7.0], np.float32)
+    d["tonemap_pbo"] = R.tonemap(films, 7.0)
+    d["rand3_seed5"] = np.stack([R.rand3(5, i * 7919, 3, i % 4) for i in range(64)])
+    np.savez_compressed(os.path.join(OUT, "units.npz"), **d)
+
+    with open(os.path.join(OUT, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == "__main__":
+    main()

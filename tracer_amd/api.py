@@ -56,6 +56,28 @@ def lib_path():
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the same as the
+    system ROCm's). A process must hold ONE HIP/HSA runtime: two copies fault inside
+    libhsa-runtime64 as soon as both touch the GPU, and streams / device pointers handed from
+    torch to this library only mean something inside torch's copy. If torch is installed but
+    not imported yet, map its copy first so that our DT_NEEDED libamdhip64.so.7 binds to it and
+    a later `import torch` finds it already loaded."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """dlopen libtracer_amd.so and declare prototypes. Raises if it has not been built."""
     global _lib
@@ -65,6 +87,7 @@ def load_library():
     if not os.path.exists(p):
         raise TracerError(f"{p} not found: build it with `make -C tracer_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(p)
     vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
     L.trc_create.argtypes = [i32, u32, u32, vp, C.POINTER(vp)]

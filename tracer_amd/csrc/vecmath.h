@@ -8,13 +8,19 @@
 // -fhip-fp32-correctly-rounded-divide-sqrt; never -ffast-math).
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cfloat>
+#include <cmath>
 
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #pragma clang fp contract(off)
-
 #define TRC_HD __host__ __device__ __forceinline__
+#else
+// host-only consumers of the scene-description API (tracer_amd/csrc/host/) built with a plain
+// C++ compiler: pass -ffp-contract=off there too.
+#define TRC_HD inline
+#endif
 
 namespace trc {
 

@@ -1,0 +1,46 @@
+"""Multi-GPU partition of a render: by sample index, one process per GPU, ONE sum-reduce of the
+film buffers at the end. The reference has no multi-GPU path; per-sample
+radiance is independent of the GPU count because the RNG is keyed by the absolute
+(pixel, iteration), so the only coupling between ranks is this final sum.
+"""
+
+
+def rank_iterations(total_iters, rank, world):
+    """Iterations {i in 1..total : (i-1) % world == rank} as (iter_first, iter_stride, count)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    if total_iters < 0:
+        raise ValueError("bad iteration count")
+    count = (total_iters - rank + world - 1) // world if total_iters > rank else 0
+    return rank + 1, world, count
+
+
+def tile_rows(height, rank, world, align=1):
+    """Optional image-tile partition: contiguous row range [y0, y1) of rank (rows aligned)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    units = (height + align - 1) // align
+    lo = units * rank // world * align
+    hi = min(height, units * (rank + 1) // world * align)
+    return lo, hi
+
+
+def reduce_film(film, dist, dst=0):
+    """The path's one collective: element-wise SUM of the per-rank films onto rank `dst`
+    (RCCL when `film` is a GPU tensor and the backend is "nccl"; gloo on CPU tensors)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+    return film
+
+
+def render_partitioned(tracer, cam, seed, total_iters, film, rank, world, dist):
+    """Render this rank's share of `total_iters` iterations into `film` (a torch tensor bound to
+    the tracer with Tracer.bind_film), sum-reduce to rank 0 and tonemap there."""
+    first, stride, count = rank_iterations(total_iters, rank, world)
+    film.zero_()
+    if count:
+        tracer.pathtrace(cam, seed, first, count, iter_stride=stride)
+    reduce_film(film, dist, 0)
+    if rank == 0:
+        tracer.tonemap(total_iters)
+    return film
