@@ -1,11 +1,41 @@
 // tracer_amd/csrc/intersect.h -- closest-hit for gfx950: the arithmetic of the reference's
 // src/Ray.inl in its exact operation order, over the flat scene records of scene.h.
+//
+// closest_hit() is WAVE-CONVERGENT: all 64 lanes of a wavefront must call it together (lanes
+// without a live path pass live = false). That lets the MESH test turn the few lanes whose ray
+// passed the AABB into wave-wide work: the triangles of a 64-triangle chunk are spread over the
+// lanes and each passing ray is broadcast to them in turn (lane <-> triangle instead of
+// lane <-> ray), with the reference's "first index wins" tie rule kept by a wave-wide
+// min + lowest-lane select.
 #pragma once
 #include "scene.h"
 
 #pragma clang fp contract(off)
 
 namespace trc {
+
+// ---- wave64 helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {   // lane must be wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned umin_dpp(unsigned v) {
+  unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false);
+  return o < v ? o : v;
+}
+// minimum over the 64 lanes, returned as a wave-uniform value (row_shr 1,2,4,8; row_bcast 15, 31)
+__device__ __forceinline__ unsigned wave_umin(unsigned v) {
+  v = umin_dpp<0x111, 0xf>(v);
+  v = umin_dpp<0x112, 0xf>(v);
+  v = umin_dpp<0x114, 0xf>(v);
+  v = umin_dpp<0x118, 0xf>(v);
+  v = umin_dpp<0x142, 0xa>(v);
+  v = umin_dpp<0x143, 0xc>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 __device__ __forceinline__ Hit no_hit() {   // Ray.inl:30  Hit() : m_t(-1), m_id(-1), vec3s zero
   Hit h; h.t = -1.0f; h.id = -1; h.pos = splat3(0.0f); h.nor = splat3(0.0f); return h;
@@ -51,87 +81,125 @@ __device__ __forceinline__ bool slab(const Ray& ray, f3 bmin, f3 bmax, float& tN
   return !(tNear > tFar || tFar < 0.0f);
 }
 
-// Object-space primitive test, Ray.inl:102-187. `t < 0` means no hit (Ray.inl:93).
-// For MESH the triangle loop runs over the pre-gathered stream in index order with the
-// reference's strict `<`, so the lowest face index wins ties (Ray.inl:174).
-__device__ __forceinline__ float hit_primitive(const Ray& r, const DevObject& o,
-                                               const DevTri* __restrict__ tris,
-                                               f3& pos, f3& nor, uint32_t& tri_tests) {
-  const int type = o.mesh_type;
-  if (type == REF_SPHERE) {                                   // Ray.inl:103-118
-    f3 l = -r.pos;
-    float s = dot(l, r.dir);
-    float l2 = dot(l, l);
-    if (s < 0.0f && l2 > 0.25f) return -1.0f;
-    float m2 = l2 - s * s;
-    if (m2 > 0.25f) return -1.0f;
-    float q = sqrtf(0.25f - m2);
-    float t = (l2 > 0.25f) ? s - q : s + q;
-    pos = r.pos + r.dir * t;
-    nor = normalize(pos);
-    return t;
-  } else if (type == REF_CUBE) {                              // Ray.inl:120-140
-    float tNear, tFar;
-    if (!slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar)) return -1.0f;
-    float t = tNear > 0.0f ? tNear : tFar;
-    pos = r.pos + r.dir * t;
-    if      (pos.x < -0.5f + kEps) nor = mk3(-1.0f, 0.0f, 0.0f);
-    else if (pos.x >  0.5f - kEps) nor = mk3( 1.0f, 0.0f, 0.0f);
-    else if (pos.y < -0.5f + kEps) nor = mk3( 0.0f, -1.0f, 0.0f);
-    else if (pos.y >  0.5f - kEps) nor = mk3( 0.0f, 1.0f, 0.0f);
-    else if (pos.z < -0.5f + kEps) nor = mk3( 0.0f, 0.0f, -1.0f);
-    else                           nor = mk3( 0.0f, 0.0f, 1.0f);
-    return t;
-  } else if (type == REF_PLANE) {                             // Ray.inl:142-158
-    float t = -r.pos.y / r.dir.y;
-    f3 p = r.pos + t * r.dir;
-    if (p.x < 0.5f && p.z < 0.5f && p.x > -0.5f && p.z > -0.5f) {
-      pos = p; nor = mk3(0.0f, 1.0f, 0.0f);
-      return t;                                               // sign tested by the caller (:93)
+// MESH, Ray.inl:160-186: brute force over the object's triangles in face order, strict `<`
+// (lowest face index wins ties, Ray.inl:174). Wave-convergent; `pass` marks the lanes whose
+// ray passed the AABB. Returns the closest positive t (FLT_MAX if none) and its normal.
+__device__ __forceinline__ float mesh_closest(const Ray& r, bool pass, const DevTri* __restrict__ tris,
+                                              uint32_t first, uint32_t count, f3& bn, uint32_t& tri_tests) {
+  float best = FLT_MAX;
+  bn = splat3(0.0f);
+  const unsigned long long mask = __ballot(pass);
+  if (mask == 0ull || count == 0u) return best;
+  const unsigned n_pass = __popcll(mask);
+  const unsigned n_chunks = (count + 63u) >> 6;
+  if (pass) tri_tests += count;
+  // cost model (VALU instructions per wave): triangle-per-lane ~ n_pass * n_chunks * 130,
+  // ray-per-lane ~ count * 95
+  if (n_pass * n_chunks * 4u <= count * 3u) {
+    const unsigned lane = lane_id();
+    const unsigned INF_BITS = 0x7f800000u;
+    for (uint32_t base = 0; base < count; base += 64u) {
+      const uint32_t ti = base + lane;
+      const bool valid = ti < count;
+      const DevTri tri = tris[first + (valid ? ti : count - 1u)];
+      unsigned long long m = mask;
+      while (m) {                                              // one passing ray at a time
+        const int L = __builtin_ctzll(m);
+        m &= m - 1ull;
+        Ray rr;
+        rr.pos = mk3(read_lane(r.pos.x, L), read_lane(r.pos.y, L), read_lane(r.pos.z, L));
+        rr.dir = mk3(read_lane(r.dir.x, L), read_lane(r.dir.y, L), read_lane(r.dir.z, L));
+        const float bestL = read_lane(best, L);
+        f3 n = splat3(0.0f);
+        const float t = hit_triangle(rr, tri, n);
+        // Ray.inl:174  thit.m_t > 0 && thit.m_t < hit.m_t ; positive floats order as their bits
+        const unsigned cand = (valid && t > 0.0f && t < bestL) ? __float_as_uint(t) : INF_BITS;
+        const unsigned tmin = wave_umin(cand);
+        if (tmin != INF_BITS) {
+          const int win = __builtin_ctzll(__ballot(cand == tmin));   // lowest lane = lowest face index
+          const float nx = read_lane(n.x, win), ny = read_lane(n.y, win), nz = read_lane(n.z, win);
+          if (lane == (unsigned)L) { best = __uint_as_float(tmin); bn = mk3(nx, ny, nz); }
+        }
+      }
     }
-    return -1.0f;
-  } else {                                                    // MESH, Ray.inl:160-186
-    float tNear, tFar;
-    if (!slab(r, o.bmin, o.bmax, tNear, tFar)) return -1.0f;
-    float best = FLT_MAX;
-    f3 bn = splat3(0.0f);
-    const uint32_t first = o.tri_first, count = o.tri_count;
+  } else if (pass) {
     for (uint32_t i = 0; i < count; ++i) {
       f3 n;
       float t = hit_triangle(r, tris[first + i], n);
       if (t > 0.0f && t < best) { best = t; bn = n; }
     }
-    tri_tests += count;
-    // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero
-    // normal forward; the world-space distance test then rejects it because
-    // |o + d*FLT_MAX|^2 overflows to inf for any normalised d.
-    if (best == FLT_MAX) return -1.0f;
-    pos = r.pos + r.dir * best;
-    nor = bn;
-    return best;
   }
+  return best;
 }
 
 // Ray::intersectScene, Ray.inl:66-84: closest by WORLD-space squared distance (not by t),
 // strict `<` so the lowest object index wins ties; the surviving t is the object-space one.
-__device__ __forceinline__ Hit closest_hit(const Ray& ray,
+// Per object: Ray::intersect(ray, obj), Ray.inl:86-100, with the primitive tests of :102-187.
+__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live,
                                            const DevObject* __restrict__ objs, uint32_t nobj,
                                            const DevTri* __restrict__ tris, uint32_t& tri_tests) {
   float mindist = FLT_MAX;
   Hit best = no_hit();
   for (uint32_t i = 0; i < nobj; ++i) {
     const DevObject& o = objs[i];
-    Ray r = to_object_space(ray, o.mi);                       // Ray.inl:88
-    f3 opos, onor;
-    float t = hit_primitive(r, o, tris, opos, onor, tri_tests);
-    if (t < 0.0f) continue;                                   // Ray.inl:93
-    // Ray.inl:59-64: position by the model matrix, normal by the model matrix too
-    // (not its inverse transpose), then normalised.
-    f3 wpos = xform_point(o.m, opos);
-    f3 wnor = normalize(xform_dir(o.m, onor));
-    if (t > 0.0f) {                                           // Ray.inl:72
-      f3 d = ray.pos - wpos;
-      float dist = dot(d, d);
+    const Ray r = to_object_space(ray, o.mi);                 // Ray.inl:88
+    const int type = o.mesh_type;
+    float t = -1.0f;                                          // t < 0: no hit (Ray.inl:93)
+    f3 opos = splat3(0.0f), wnor = splat3(0.0f);
+    if (type == REF_PLANE) {                                  // Ray.inl:142-158
+      const float tp = -r.pos.y / r.dir.y;
+      const f3 p = r.pos + tp * r.dir;
+      if (p.x < 0.5f && p.z < 0.5f && p.x > -0.5f && p.z > -0.5f) { t = tp; opos = p; }
+      wnor = o.axis_nor[3];                                   // (0,1,0) through Ray.inl:62
+    } else if (type == REF_SPHERE) {                          // Ray.inl:103-118
+      const f3 l = -r.pos;
+      const float s = dot(l, r.dir);
+      const float l2 = dot(l, l);
+      const float m2 = l2 - s * s;
+      if (!(s < 0.0f && l2 > 0.25f) && !(m2 > 0.25f)) {
+        const float q = sqrtf(0.25f - m2);
+        t = (l2 > 0.25f) ? s - q : s + q;
+        opos = r.pos + r.dir * t;
+        if (!(t < 0.0f)) wnor = normalize(xform_dir(o.m, normalize(opos)));   // Ray.inl:116, :62
+      }
+    } else if (type == REF_CUBE) {                            // Ray.inl:120-140
+      float tNear, tFar;
+      if (slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar)) {
+        t = tNear > 0.0f ? tNear : tFar;
+        opos = r.pos + r.dir * t;
+        int k;
+        if      (opos.x < -0.5f + kEps) k = 0;
+        else if (opos.x >  0.5f - kEps) k = 1;
+        else if (opos.y < -0.5f + kEps) k = 2;
+        else if (opos.y >  0.5f - kEps) k = 3;
+        else if (opos.z < -0.5f + kEps) k = 4;
+        else                            k = 5;
+        // the six candidates are wave-uniform (SGPR) values: select, do not index
+        wnor = o.axis_nor[0];
+        if (k == 1) wnor = o.axis_nor[1];
+        if (k == 2) wnor = o.axis_nor[2];
+        if (k == 3) wnor = o.axis_nor[3];
+        if (k == 4) wnor = o.axis_nor[4];
+        if (k == 5) wnor = o.axis_nor[5];
+      }
+    } else {                                                  // MESH, Ray.inl:160-186
+      float tNear, tFar;
+      const bool pass = live && slab(r, o.bmin, o.bmax, tNear, tFar);
+      f3 bn;
+      const float tb = mesh_closest(r, pass, tris, o.tri_first, o.tri_count, bn, tri_tests);
+      // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero
+      // normal forward; the world-space distance test then rejects it because
+      // |o + d*FLT_MAX|^2 overflows to inf for any normalised d.
+      if (pass && tb != FLT_MAX) {
+        t = tb;
+        opos = r.pos + r.dir * tb;
+        wnor = normalize(xform_dir(o.m, bn));                 // Ray.inl:62
+      }
+    }
+    if (t > 0.0f) {                                           // Ray.inl:93 (t >= 0 transforms), :72 (t > 0 competes)
+      const f3 wpos = xform_point(o.m, opos);                 // Ray.inl:61
+      const f3 d = ray.pos - wpos;
+      const float dist = dot(d, d);
       if (dist < mindist) { mindist = dist; best.t = t; best.id = (int)i; best.pos = wpos; best.nor = wnor; }
     }
   }

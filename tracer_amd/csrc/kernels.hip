@@ -19,9 +19,6 @@ namespace trc {
 constexpr int kBlock = 256;
 
 // ---- wave64 helpers ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned lane_id() {
-  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -64,11 +61,14 @@ __device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx
 }
 
 // ---- one bounce (calcColorKernel body, raytrace.cu:126-159) -------------------------------------
-enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2 };
+// Wave-convergent: every lane of the wavefront calls it; lanes with live == false run along
+// (their result is STEP_IDLE and their ray/col are left untouched).
+enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE = 3 };
 
-__device__ __forceinline__ int bounce_step(const FrameParams& fp, uint32_t pixel, uint32_t iter, int depth,
+__device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uint32_t pixel, uint32_t iter, int depth,
                                            Ray& ray, f3& col, uint32_t& tri_tests) {
-  Hit hit = closest_hit(ray, fp.objs, fp.nobj, fp.tris, tri_tests);
+  Hit hit = closest_hit(ray, live, fp.objs, fp.nobj, fp.tris, tri_tests);
+  if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
   const DevObject& o = fp.objs[hit.id];
   const f3 mcolor = o.color;
@@ -94,10 +94,11 @@ __global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* 
                                                      int32_t* __restrict__ hit_id, float* __restrict__ hit_t,
                                                      float* __restrict__ hit_pos, float* __restrict__ hit_nor) {
   uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= fp.npix) return;
+  const bool valid = idx < fp.npix;          // no early return: closest_hit is wave-convergent
   Ray ray = primary_ray(fp, idx);
   uint32_t tt = 0;
-  Hit hit = closest_hit(ray, fp.objs, fp.nobj, fp.tris, tt);
+  Hit hit = closest_hit(ray, valid, fp.objs, fp.nobj, fp.tris, tt);
+  if (!valid) return;
   const f3 lightDir = mk3((float)0.267261, (float)0.801784, (float)0.534522);
   f3 col;
   if (hit.id < 0) col = ray.dir;
@@ -149,18 +150,18 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
   if (blockIdx.x * kBlock >= n_in) return;                            // whole block past the queue
   int32_t pixel = (i < n_in) ? cur.pixel[i] : -1;
   const bool active = pixel >= 0;                                     // raytrace.cu:119-124
-  bool cont = false;
-  Ray ray; f3 col = splat3(0.0f);
+  Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
+  f3 col = splat3(0.0f);
   uint32_t tt = 0;
   if (active) {
     ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]);
     ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
     col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
-    int res = bounce_step(fp, (uint32_t)pixel, iter, depth, ray, col, tt);
-    cont = (res == STEP_CONTINUE);
-    if (res == STEP_LIGHT) {                                          // the only non-black ending
-      film[3 * pixel] += col.x; film[3 * pixel + 1] += col.y; film[3 * pixel + 2] += col.z;
-    }
+  }
+  const int res = bounce_step(fp, active, active ? (uint32_t)pixel : 0u, iter, depth, ray, col, tt);
+  const bool cont = (res == STEP_CONTINUE);
+  if (res == STEP_LIGHT) {                                            // the only non-black ending
+    film[3 * pixel] += col.x; film[3 * pixel + 1] += col.y; film[3 * pixel + 2] += col.z;
   }
   if (COMPACT) {
     // compaction by wavefront ballot: rank within the wave from the ballot mask, one atomic
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
 // One lane owns one pixel for the whole call. Its ray, throughput and film sum stay in VGPRs;
 // a lane whose path ended starts that pixel's next iteration at once (path regeneration), so
 // every trip of the loop is one closest-hit evaluation for (nearly) all 64 lanes.
-__global__ __launch_bounds__(kBlock) void k_fused(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
+__global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                  uint32_t n_iters, float* __restrict__ film,
                                                  DeviceCounters* counters) {
   const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
@@ -222,17 +223,15 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameParams fp, uint32_t iter_
       need_new = false;
     }
     if (__ballot(!done) == 0ull) break;
-    if (!done) {
+    const int res = bounce_step(fp, !done, pixel, iter, depth, ray, col, tt);
+    if (res == STEP_CONTINUE) {
+      ++live; ++depth;
+    } else if (res != STEP_IDLE) {
       ++live;
-      int res = bounce_step(fp, pixel, iter, depth, ray, col, tt);
-      if (res == STEP_CONTINUE) {
-        ++depth;
-      } else {
-        if (res == STEP_LIGHT) acc = acc + col;                       // film += col, raytrace.cu:170
-        ++k;
-        need_new = true;
-        done = (k == n_iters);
-      }
+      if (res == STEP_LIGHT) acc = acc + col;                         // film += col, raytrace.cu:170
+      ++k;
+      need_new = true;
+      done = (k == n_iters);
     }
   }
   if (valid) { film[3 * pixel] = acc.x; film[3 * pixel + 1] = acc.y; film[3 * pixel + 2] = acc.z; }

@@ -35,7 +35,7 @@ static_assert(sizeof(RefMaterial) == 28, "Material::Material layout");
 static_assert(sizeof(RefObject) == 168, "Object::Object layout");
 
 // ---- device-side layout -------------------------------------------------------------------
-// One 160-byte record per object, read with wave-uniform (scalar) loads: every lane of a
+// One 240-byte record per object, read with wave-uniform (scalar) loads: every lane of a
 // wavefront walks the same object list (Ray.inl:70), so the record lives in SGPRs.
 struct alignas(16) DevObject {
   Affine   mi;           // world -> object, 12 floats   (Object::m_matrixi)
@@ -50,8 +50,14 @@ struct alignas(16) DevObject {
   float    ior;          // Material::m_n
   int32_t  mat_type;     // RefMatType
   int32_t  mesh_type;    // RefMeshType
+  // World-space normals of the axis-aligned object-space normals, i.e. what Ray.inl:62
+  // normalize(vec3(m_matrix * vec4(n, 0))) yields for n = -x,+x,-y,+y,-z,+z. PLANE always
+  // reports +y (Ray.inl:151) and CUBE one of the six (Ray.inl:132-137), so the per-ray matrix
+  // product + normalisation is replaced by a table filled on the host with the same IEEE ops.
+  f3       axis_nor[6];
+  float    pad_[2];
 };
-static_assert(sizeof(DevObject) == 160, "DevObject");
+static_assert(sizeof(DevObject) == 240, "DevObject");
 
 // Triangle stream: faces pre-gathered at upload (replaces the Face -> verts/norms double
 // indirection of Mesh::getTriangle, Mesh.inl:50-65) into 80-byte records that are contiguous

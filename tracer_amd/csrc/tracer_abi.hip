@@ -115,6 +115,13 @@ FrameParams make_params(const trc_ctx* c, const trc_camera* cam, uint64_t seed) 
   return fp;
 }
 
+// Ray.inl:62 for the six axis-aligned object-space normals (see DevObject::axis_nor).
+void fill_axis_normals(DevObject& d) {
+  const f3 axes[6] = { mk3(-1.0f, 0.0f, 0.0f), mk3(1.0f, 0.0f, 0.0f), mk3(0.0f, -1.0f, 0.0f),
+                       mk3(0.0f, 1.0f, 0.0f), mk3(0.0f, 0.0f, -1.0f), mk3(0.0f, 0.0f, 1.0f) };
+  for (int k = 0; k < 6; ++k) d.axis_nor[k] = normalize(xform_dir(d.m, axes[k]));
+}
+
 // Flatten the caller's Object[]/Mesh AoS into DevObject records + one triangle stream.
 int flatten_scene(const RefObject* objs, uint32_t count, std::vector<DevObject>& out_objs,
                   std::vector<DevTri>& out_tris) {
@@ -136,6 +143,7 @@ int flatten_scene(const RefObject* objs, uint32_t count, std::vector<DevObject>&
       return fail(TRC_ERR_INVALID, "object " + std::to_string(i) + ": unknown MeshType");
     if (d.mat_type < REF_DIFF || d.mat_type > REF_MIRR)
       return fail(TRC_ERR_INVALID, "object " + std::to_string(i) + ": unknown Material::Type");
+    fill_axis_normals(d);
     d.tri_first = (uint32_t)out_tris.size();
     d.tri_count = 0;
     if (d.mesh_type == REF_MESH) {
@@ -266,6 +274,7 @@ int trc_update_object(trc_ctx* c, uint32_t index, const float matrix[16], const 
   DevObject& d = c->objs_h[index];
   affine_from_mat4(d.m, matrix);
   affine_from_mat4(d.mi, matrixi);
+  fill_axis_normals(d);
   // stream-ordered like the reference's cudaMemcpy on the default stream (Renderer.cpp:224)
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpy(c->objs_d + index, &d, sizeof(DevObject), hipMemcpyHostToDevice));
