@@ -14,7 +14,8 @@ sc = ta.Scene(0)
 cam = ta.camera_default(w, h)
 tr = ta.Tracer(w, h)
 tr.set_pipeline(pipe)
-tr.upload_scene(sc.objects_ptr, sc.size)
+nobj = int(os.environ.get('TRC_NOBJ', sc.size))
+tr.upload_scene(sc.objects_ptr, nobj)
 for r in range(reps):
     tr.reset_counters()
     tr.pathtrace(cam, 1, 1, iters)

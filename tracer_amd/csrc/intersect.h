@@ -132,78 +132,118 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, bool pass, const Dev
   return best;
 }
 
-// Ray::intersectScene, Ray.inl:66-84: closest by WORLD-space squared distance (not by t),
-// strict `<` so the lowest object index wins ties; the surviving t is the object-space one.
-// Per object: Ray::intersect(ray, obj), Ray.inl:86-100, with the primitive tests of :102-187.
-__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live,
-                                           const DevObject* __restrict__ objs, uint32_t nobj,
-                                           const DevTri* __restrict__ tris, uint32_t& tri_tests) {
-  float mindist = FLT_MAX;
-  Hit best = no_hit();
-  for (uint32_t i = 0; i < nobj; ++i) {
-    const DevObject& o = objs[i];
-    const Ray r = to_object_space(ray, o.mi);                 // Ray.inl:88
-    const int type = o.mesh_type;
-    float t = -1.0f;                                          // t < 0: no hit (Ray.inl:93)
-    f3 opos = splat3(0.0f), wnor = splat3(0.0f);
-    if (type == REF_PLANE) {                                  // Ray.inl:142-158
-      const float tp = -r.pos.y / r.dir.y;
-      const f3 p = r.pos + tp * r.dir;
-      if (p.x < 0.5f && p.z < 0.5f && p.x > -0.5f && p.z > -0.5f) { t = tp; opos = p; }
-      wnor = o.axis_nor[3];                                   // (0,1,0) through Ray.inl:62
-    } else if (type == REF_SPHERE) {                          // Ray.inl:103-118
-      const f3 l = -r.pos;
-      const float s = dot(l, r.dir);
-      const float l2 = dot(l, l);
-      const float m2 = l2 - s * s;
-      if (!(s < 0.0f && l2 > 0.25f) && !(m2 > 0.25f)) {
-        const float q = sqrtf(0.25f - m2);
-        t = (l2 > 0.25f) ? s - q : s + q;
-        opos = r.pos + r.dir * t;
-        if (!(t < 0.0f)) wnor = normalize(xform_dir(o.m, normalize(opos)));   // Ray.inl:116, :62
-      }
-    } else if (type == REF_CUBE) {                            // Ray.inl:120-140
-      float tNear, tFar;
-      if (slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar)) {
-        t = tNear > 0.0f ? tNear : tFar;
-        opos = r.pos + r.dir * t;
-        int k;
-        if      (opos.x < -0.5f + kEps) k = 0;
-        else if (opos.x >  0.5f - kEps) k = 1;
-        else if (opos.y < -0.5f + kEps) k = 2;
-        else if (opos.y >  0.5f - kEps) k = 3;
-        else if (opos.z < -0.5f + kEps) k = 4;
-        else                            k = 5;
-        // the six candidates are wave-uniform (SGPR) values: select, do not index
-        wnor = o.axis_nor[0];
-        if (k == 1) wnor = o.axis_nor[1];
-        if (k == 2) wnor = o.axis_nor[2];
-        if (k == 3) wnor = o.axis_nor[3];
-        if (k == 4) wnor = o.axis_nor[4];
-        if (k == 5) wnor = o.axis_nor[5];
-      }
-    } else {                                                  // MESH, Ray.inl:160-186
-      float tNear, tFar;
-      const bool pass = live && slab(r, o.bmin, o.bmax, tNear, tFar);
-      f3 bn;
-      const float tb = mesh_closest(r, pass, tris, o.tri_first, o.tri_count, bn, tri_tests);
-      // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero
-      // normal forward; the world-space distance test then rejects it because
-      // |o + d*FLT_MAX|^2 overflows to inf for any normalised d.
-      if (pass && tb != FLT_MAX) {
-        t = tb;
-        opos = r.pos + r.dir * tb;
-        wnor = normalize(xform_dir(o.m, bn));                 // Ray.inl:62
-      }
-    }
-    if (t > 0.0f) {                                           // Ray.inl:93 (t >= 0 transforms), :72 (t > 0 competes)
-      const f3 wpos = xform_point(o.m, opos);                 // Ray.inl:61
-      const f3 d = ray.pos - wpos;
-      const float dist = dot(d, d);
-      if (dist < mindist) { mindist = dist; best.t = t; best.id = (int)i; best.pos = wpos; best.nor = wnor; }
-    }
+// ---- closest hit ---------------------------------------------------------------------------------
+// Ray::intersectScene, Ray.inl:66-84: closest by WORLD-space squared distance (not by t); the
+// surviving t is the object-space one. The reference walks objects in index order with a strict
+// `<`, i.e. among equal distances the LOWEST index wins; objects are visited here grouped by
+// type, so the same winner is selected by comparing (distance, original index).
+struct Closest {
+  float mindist; float t; int id; f3 pos, nor;
+};
+
+// Ray.inl:93 (t >= 0 gets transformed), :72 (t > 0 competes), :59-64 (hit to world space)
+__device__ __forceinline__ void consider(Closest& c, const Ray& ray, float t, uint32_t id,
+                                         const Affine& m, f3 opos, f3 wnor) {
+  const f3 wpos = xform_point(m, opos);                       // Ray.inl:61
+  const f3 d = ray.pos - wpos;
+  const float dist = dot(d, d);                               // Ray.inl:73-74
+  const bool better = (t > 0.0f) & ((dist < c.mindist) | ((dist == c.mindist) & ((int)id < c.id)));
+  if (better) { c.mindist = dist; c.t = t; c.id = (int)id; c.pos = wpos; c.nor = wnor; }
+}
+
+// K planes at once, branch-free. Ray.inl:142-158: t = -o.y/d.y, hit iff |x|,|z| < 0.5 (strict);
+// the normal is always object +y -> DevXform::nor_y.
+template <int K>
+__device__ __forceinline__ void planes(Closest& c, const Ray& ray, const DevXform* __restrict__ xf) {
+  Ray r[K]; float t[K]; f3 p[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[k].mi);          // Ray.inl:88
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float tp = -r[k].pos.y / r[k].dir.y;
+    p[k] = r[k].pos + tp * r[k].dir;
+    const bool in = (p[k].x < 0.5f) & (p[k].z < 0.5f) & (p[k].x > -0.5f) & (p[k].z > -0.5f);
+    t[k] = in ? tp : -1.0f;
   }
-  return best;
+#pragma unroll
+  for (int k = 0; k < K; ++k) consider(c, ray, t[k], xf[k].id, xf[k].m, p[k], xf[k].nor_y);
+}
+
+// K spheres at once. Ray.inl:103-118: radius 0.5, geometric method, normal = normalize(pos),
+// then Ray.inl:62 normalize(M * (n, 0)).
+template <int K>
+__device__ __forceinline__ void spheres(Closest& c, const Ray& ray, const DevXform* __restrict__ xf) {
+  Ray r[K]; float t[K]; f3 p[K], wn[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[k].mi);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const f3 l = -r[k].pos;
+    const float s = dot(l, r[k].dir);
+    const float l2 = dot(l, l);
+    const float m2 = l2 - s * s;
+    const bool hit = !((s < 0.0f) & (l2 > 0.25f)) & !(m2 > 0.25f);
+    const float q = sqrtf(0.25f - m2);
+    const float th = (l2 > 0.25f) ? s - q : s + q;
+    t[k] = hit ? th : -1.0f;
+    p[k] = r[k].pos + r[k].dir * th;
+    wn[k] = normalize(xform_dir(xf[k].m, normalize(p[k])));
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) consider(c, ray, t[k], xf[k].id, xf[k].m, p[k], wn[k]);
+}
+
+// Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
+// -x,+x,-y,+y,-z,else +z, taken from the per-object table of world normals.
+__device__ __forceinline__ void cube(Closest& c, const Ray& ray, const DevXform& xf, const DevCubeExtra& ex) {
+  const Ray r = to_object_space(ray, xf.mi);
+  float tNear, tFar;
+  const bool hit = slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar);
+  const float th = tNear > 0.0f ? tNear : tFar;
+  const f3 p = r.pos + r.dir * th;
+  // six wave-uniform candidates: select from the last test to the first
+  f3 wn = ex.axis_nor[5];
+  if (p.z < -0.5f + kEps) wn = ex.axis_nor[4];
+  if (p.y >  0.5f - kEps) wn = ex.axis_nor[3];
+  if (p.y < -0.5f + kEps) wn = ex.axis_nor[2];
+  if (p.x >  0.5f - kEps) wn = ex.axis_nor[1];
+  if (p.x < -0.5f + kEps) wn = ex.axis_nor[0];
+  consider(c, ray, hit ? th : -1.0f, xf.id, xf.m, p, wn);
+}
+
+// Ray.inl:160-186 (MESH): AABB slab test, then mesh_closest().
+__device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, const DevXform& xf,
+                                     const DevMeshExtra& ex, const DevTri* __restrict__ tris, uint32_t& tri_tests) {
+  const Ray r = to_object_space(ray, xf.mi);
+  float tNear, tFar;
+  const bool pass = live && slab(r, ex.bmin, ex.bmax, tNear, tFar);
+  f3 bn;
+  const float tb = mesh_closest(r, pass, tris, ex.tri_first, ex.tri_count, bn, tri_tests);
+  // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero normal
+  // forward; the world-space distance test then rejects it because |o + d*FLT_MAX|^2 overflows
+  // to inf for any normalised d -> explicit miss here.
+  const bool hit = pass && tb != FLT_MAX;
+  const f3 p = r.pos + r.dir * tb;
+  const f3 wn = normalize(xform_dir(xf.m, bn));               // Ray.inl:62
+  consider(c, ray, hit ? tb : -1.0f, xf.id, xf.m, p, wn);
+}
+
+// Wave-convergent (see the header comment).
+__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevScene& sc, uint32_t& tri_tests) {
+  Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
+  const DevXform* __restrict__ xf = sc.xf;
+  uint32_t i = 0;
+  for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, xf + i);
+  if (i < sc.n_plane) planes<1>(c, ray, xf + i);
+  xf += sc.n_plane;
+  for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, xf + i);
+  if (i < sc.n_sphere) spheres<1>(c, ray, xf + i);
+  xf += sc.n_sphere;
+  for (i = 0; i < sc.n_cube; ++i) cube(c, ray, xf[i], sc.cubes[i]);
+  xf += sc.n_cube;
+  for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc.tris, tri_tests);
+  Hit h; h.t = c.t; h.id = c.id; h.pos = c.pos; h.nor = c.nor;
+  return h;
 }
 
 } // namespace trc

@@ -13,9 +13,7 @@ struct FrameParams {
   f3 campos, A, B, C;       // raytrace.cu:192
   f3 nA, nB;                // normalize(A), normalize(B) of raytrace.cu:94, hoisted to the host
   float lensRadius, focalDist;
-  const DevObject* objs;    // scene records (scene.h)
-  const DevTri* tris;       // triangle stream
-  uint32_t nobj;
+  DevScene sc;              // packed scene (scene.h)
   uint32_t seed_lo, seed_hi;
   int rng_mode;             // trc_rng_mode
 };

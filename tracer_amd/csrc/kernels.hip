@@ -67,10 +67,10 @@ enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE =
 
 __device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uint32_t pixel, uint32_t iter, int depth,
                                            Ray& ray, f3& col, uint32_t& tri_tests) {
-  Hit hit = closest_hit(ray, live, fp.objs, fp.nobj, fp.tris, tri_tests);
+  Hit hit = closest_hit(ray, live, fp.sc, tri_tests);
   if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
-  const DevObject& o = fp.objs[hit.id];
+  const DevMaterial& o = fp.sc.mats[hit.id];
   const f3 mcolor = o.color;
   const float emit = o.emit;
   if (emit > 0.0f) { col = col * (mcolor * emit); return STEP_LIGHT; }      // :137-141
@@ -97,13 +97,13 @@ __global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* 
   const bool valid = idx < fp.npix;          // no early return: closest_hit is wave-convergent
   Ray ray = primary_ray(fp, idx);
   uint32_t tt = 0;
-  Hit hit = closest_hit(ray, valid, fp.objs, fp.nobj, fp.tris, tt);
+  Hit hit = closest_hit(ray, valid, fp.sc, tt);
   if (!valid) return;
   const f3 lightDir = mk3((float)0.267261, (float)0.801784, (float)0.534522);
   f3 col;
   if (hit.id < 0) col = ray.dir;
   else {
-    const DevObject& o = fp.objs[hit.id];
+    const DevMaterial& o = fp.sc.mats[hit.id];
     if (o.emit > 0.0f) col = o.color;
     else {
       col = o.color * o.brdf;

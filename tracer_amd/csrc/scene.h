@@ -34,9 +34,7 @@ static_assert(sizeof(RefMesh) == 72, "Mesh::Mesh layout");
 static_assert(sizeof(RefMaterial) == 28, "Material::Material layout");
 static_assert(sizeof(RefObject) == 168, "Object::Object layout");
 
-// ---- device-side layout -------------------------------------------------------------------
-// One 240-byte record per object, read with wave-uniform (scalar) loads: every lane of a
-// wavefront walks the same object list (Ray.inl:70), so the record lives in SGPRs.
+// ---- flattened object (host-side intermediate, one per caller object, original order) ------
 struct alignas(16) DevObject {
   Affine   mi;           // world -> object, 12 floats   (Object::m_matrixi)
   Affine   m;            // object -> world, 12 floats   (Object::m_matrix)
@@ -58,6 +56,37 @@ struct alignas(16) DevObject {
   float    pad_[2];
 };
 static_assert(sizeof(DevObject) == 240, "DevObject");
+
+// ---- device-side layout -------------------------------------------------------------------
+// Objects are GROUPED BY PRIMITIVE TYPE on the device: [planes | spheres | cubes | meshes].
+// Every lane of a wavefront walks the same object list (Ray.inl:70), so a record is read with
+// wave-uniform scalar loads into SGPRs; grouping lets the kernel run type-specialised,
+// branch-free loops that test two objects of one type per trip (two independent dependency
+// chains for the VALU to interleave). The reference's tie rule "lowest object index wins"
+// (strict `<` in index order, Ray.inl:75) is kept by comparing (distance, original index).
+struct alignas(16) DevXform {      // 128 bytes = two s_load_dwordx16
+  Affine   mi;                     // world -> object (Object::m_matrixi)
+  Affine   m;                      // object -> world (Object::m_matrix)
+  f3       nor_y;                  // world normal of object-space +y: what a PLANE hit reports
+  uint32_t id;                     // index in the caller's Object[] (Hit::m_id)
+  uint32_t pad[4];
+};
+static_assert(sizeof(DevXform) == 128, "DevXform");
+struct alignas(16) DevCubeExtra { f3 axis_nor[6]; float pad[2]; };                 // 80 bytes
+struct alignas(16) DevMeshExtra { f3 bmin; uint32_t tri_first; f3 bmax; uint32_t tri_count; };
+struct alignas(16) DevMaterial  { f3 color; float emit; float brdf; float ior; int32_t mat_type; int32_t pad; };
+static_assert(sizeof(DevCubeExtra) == 80 && sizeof(DevMeshExtra) == 32 && sizeof(DevMaterial) == 32, "extras");
+
+struct DevTri;
+// Pointers into ONE device allocation holding the packed scene.
+struct DevScene {
+  const DevXform*     xf;          // n_plane + n_sphere + n_cube + n_mesh records, in that order
+  const DevCubeExtra* cubes;       // n_cube
+  const DevMeshExtra* meshes;      // n_mesh
+  const DevMaterial*  mats;        // nobj, indexed by ORIGINAL object index
+  const DevTri*       tris;        // triangle stream
+  uint32_t n_plane, n_sphere, n_cube, n_mesh;
+};
 
 // Triangle stream: faces pre-gathered at upload (replaces the Face -> verts/norms double
 // indirection of Mesh::getTriangle, Mesh.inl:50-65) into 80-byte records that are contiguous

@@ -49,11 +49,13 @@ struct trc_ctx {
   int pipeline = TRC_PIPE_FUSED;
   int record_hits = 1;
 
-  // scene
-  DevObject* objs_d = nullptr;
-  DevTri* tris_d = nullptr;
+  // scene: one device allocation [xforms | cube extras | mesh extras | materials | triangles]
+  void* scene_d = nullptr;
+  size_t scene_cap = 0;
+  DevScene sc = {};
   uint32_t nobj = 0;
-  std::vector<DevObject> objs_h;
+  std::vector<DevObject> objs_h;     // flattened objects, caller order (for trc_update_object)
+  std::vector<DevTri> tris_h;
 
   // outputs
   float* film_own = nullptr;   // 3*npix
@@ -109,7 +111,7 @@ FrameParams make_params(const trc_ctx* c, const trc_camera* cam, uint64_t seed) 
   fp.nA = normalize(fp.A);       // raytrace.cu:94 evaluates these per thread; same IEEE ops here
   fp.nB = normalize(fp.B);
   fp.lensRadius = cam->lensRadius; fp.focalDist = cam->focalDist;
-  fp.objs = c->objs_d; fp.tris = c->tris_d; fp.nobj = c->nobj;
+  fp.sc = c->sc;
   fp.seed_lo = (uint32_t)seed; fp.seed_hi = (uint32_t)(seed >> 32);
   fp.rng_mode = c->rng_mode;
   return fp;
@@ -171,6 +173,83 @@ int flatten_scene(const RefObject* objs, uint32_t count, std::vector<DevObject>&
   return TRC_OK;
 }
 
+// Group the flattened objects by primitive type and lay everything out in one buffer
+// (scene.h: DevScene). `base` is the device address the buffer will live at.
+size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>& tris,
+                  std::vector<unsigned char>& blob) {
+  std::vector<DevXform> xf; std::vector<DevCubeExtra> cubes; std::vector<DevMeshExtra> meshes;
+  std::vector<DevMaterial> mats(objs.size());
+  const int order[4] = { REF_PLANE, REF_SPHERE, REF_CUBE, REF_MESH };
+  for (int g = 0; g < 4; ++g)
+    for (size_t i = 0; i < objs.size(); ++i) {
+      const DevObject& o = objs[i];
+      if (o.mesh_type != order[g]) continue;
+      DevXform x; memset(&x, 0, sizeof x);
+      x.mi = o.mi; x.m = o.m; x.nor_y = o.axis_nor[3]; x.id = (uint32_t)i;
+      xf.push_back(x);
+      if (o.mesh_type == REF_CUBE) {
+        DevCubeExtra e; memset(&e, 0, sizeof e);
+        for (int k = 0; k < 6; ++k) e.axis_nor[k] = o.axis_nor[k];
+        cubes.push_back(e);
+      } else if (o.mesh_type == REF_MESH) {
+        DevMeshExtra e; e.bmin = o.bmin; e.tri_first = o.tri_first; e.bmax = o.bmax; e.tri_count = o.tri_count;
+        meshes.push_back(e);
+      }
+    }
+  for (size_t i = 0; i < objs.size(); ++i) {
+    DevMaterial& m = mats[i]; memset(&m, 0, sizeof m);
+    m.color = objs[i].color; m.emit = objs[i].emit; m.brdf = objs[i].brdf; m.ior = objs[i].ior; m.mat_type = objs[i].mat_type;
+  }
+  auto append = [&](const void* p, size_t n) {
+    size_t off = blob.size();
+    blob.resize(off + ((n + 255) & ~size_t(255)));             // keep every section 256-byte aligned
+    if (n) memcpy(blob.data() + off, p, n);
+    return off;
+  };
+  blob.clear();
+  append(xf.data(), xf.size() * sizeof(DevXform));
+  append(cubes.data(), cubes.size() * sizeof(DevCubeExtra));
+  append(meshes.data(), meshes.size() * sizeof(DevMeshExtra));
+  append(mats.data(), mats.size() * sizeof(DevMaterial));
+  append(tris.data(), tris.size() * sizeof(DevTri));
+  blob.resize(blob.size() + 256);                              // slack: empty sections still get valid addresses
+  return blob.size();
+}
+
+DevScene scene_pointers(const std::vector<DevObject>& objs, const std::vector<DevTri>& tris, void* base) {
+  DevScene sc; memset(&sc, 0, sizeof sc);
+  for (const DevObject& o : objs) {
+    if (o.mesh_type == REF_PLANE) ++sc.n_plane; else if (o.mesh_type == REF_SPHERE) ++sc.n_sphere;
+    else if (o.mesh_type == REF_CUBE) ++sc.n_cube; else ++sc.n_mesh;
+  }
+  auto up = [](size_t n) { return (n + 255) & ~size_t(255); };
+  unsigned char* p = (unsigned char*)base;
+  sc.xf = (const DevXform*)p;         p += up(objs.size() * sizeof(DevXform));
+  sc.cubes = (const DevCubeExtra*)p;  p += up(sc.n_cube * sizeof(DevCubeExtra));
+  sc.meshes = (const DevMeshExtra*)p; p += up(sc.n_mesh * sizeof(DevMeshExtra));
+  sc.mats = (const DevMaterial*)p;    p += up(objs.size() * sizeof(DevMaterial));
+  sc.tris = (const DevTri*)p;
+  (void)tris;
+  return sc;
+}
+
+// (Re)upload the packed scene; grows the device allocation when needed.
+int upload_packed(void*& dev, size_t& cap, DevScene& sc, const std::vector<DevObject>& objs,
+                  const std::vector<DevTri>& tris, bool objects_only) {
+  std::vector<unsigned char> blob;
+  const size_t bytes = pack_scene(objs, tris, blob);
+  if (bytes > cap) {
+    if (dev) { (void)hipFree(dev); dev = nullptr; cap = 0; }
+    HIP_TRY(hipMalloc(&dev, bytes));
+    cap = bytes;
+    objects_only = false;
+  }
+  sc = scene_pointers(objs, tris, dev);
+  const size_t n = objects_only ? (size_t)((const unsigned char*)sc.tris - (const unsigned char*)dev) : bytes;
+  HIP_TRY(hipMemcpy(dev, blob.data(), n, hipMemcpyHostToDevice));
+  return TRC_OK;
+}
+
 int begin_timing(trc_ctx* c) { HIP_TRY(hipEventRecord(c->ev_start, c->stream)); return TRC_OK; }
 int end_timing(trc_ctx* c) { HIP_TRY(hipEventRecord(c->ev_stop, c->stream)); c->timed = true; return TRC_OK; }
 
@@ -217,7 +296,7 @@ int trc_destroy(trc_ctx* c) {
   if (!c) return TRC_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  free_dev(c->objs_d); free_dev(c->tris_d);
+  free_dev(c->scene_d);
   free_dev(c->film_own); free_dev(c->ldr);
   free_dev(c->hit_id); free_dev(c->hit_t); free_dev(c->hit_pos); free_dev(c->hit_nor);
   free_dev(c->state_mem[0]); free_dev(c->state_mem[1]); free_dev(c->queue_count);
@@ -253,15 +332,11 @@ int trc_upload_scene(trc_ctx* c, const void* objects, uint32_t count) {
   if (rc != TRC_OK) return rc;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  free_dev(c->objs_d); free_dev(c->tris_d);
   c->nobj = 0;
-  HIP_TRY(hipMalloc((void**)&c->objs_d, sizeof(DevObject) * objs.size()));
-  // always allocate one record so the kernels get a valid base pointer
-  HIP_TRY(hipMalloc((void**)&c->tris_d, sizeof(DevTri) * (tris.empty() ? 1 : tris.size())));
-  HIP_TRY(hipMemcpy(c->objs_d, objs.data(), sizeof(DevObject) * objs.size(), hipMemcpyHostToDevice));
-  if (!tris.empty())
-    HIP_TRY(hipMemcpy(c->tris_d, tris.data(), sizeof(DevTri) * tris.size(), hipMemcpyHostToDevice));
+  rc = upload_packed(c->scene_d, c->scene_cap, c->sc, objs, tris, false);
+  if (rc != TRC_OK) return rc;
   c->objs_h.swap(objs);
+  c->tris_h.swap(tris);
   c->nobj = count;
   return TRC_OK;
 }
@@ -277,8 +352,7 @@ int trc_update_object(trc_ctx* c, uint32_t index, const float matrix[16], const 
   fill_axis_normals(d);
   // stream-ordered like the reference's cudaMemcpy on the default stream (Renderer.cpp:224)
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemcpy(c->objs_d + index, &d, sizeof(DevObject), hipMemcpyHostToDevice));
-  return TRC_OK;
+  return upload_packed(c->scene_d, c->scene_cap, c->sc, c->objs_h, c->tris_h, true);
 }
 
 int trc_raytrace1(trc_ctx* c, const trc_camera* cam) {
@@ -455,8 +529,8 @@ struct LegacyMesh {
 
 struct LegacyScene {
   std::vector<const void*> mesh_keys;   // device Mesh pointers the triangle stream was built from
-  DevObject* objs_d = nullptr; uint32_t objs_cap = 0;
-  DevTri* tris_d = nullptr;
+  void* scene_d = nullptr; size_t scene_cap = 0;
+  DevScene sc = {};
   DeviceCounters* counters = nullptr;
 };
 
@@ -494,19 +568,10 @@ int legacy_prepare(const void* scene_d, uint32_t sceneSize, LegacyScene** out) {
   std::vector<DevObject> dobjs; std::vector<DevTri> dtris;
   int rc = flatten_scene(objs.data(), sceneSize, dobjs, dtris);
   if (rc) return rc;
-  if (ls->objs_cap < sceneSize) {
-    free_dev(ls->objs_d);
-    HIP_TRY(hipMalloc((void**)&ls->objs_d, sizeof(DevObject) * sceneSize));
-    ls->objs_cap = sceneSize;
-  }
-  HIP_TRY(hipMemcpy(ls->objs_d, dobjs.data(), sizeof(DevObject) * sceneSize, hipMemcpyHostToDevice));
-  if (ls->mesh_keys != keys || !ls->tris_d) {
-    free_dev(ls->tris_d);
-    HIP_TRY(hipMalloc((void**)&ls->tris_d, sizeof(DevTri) * (dtris.empty() ? 1 : dtris.size())));
-    if (!dtris.empty())
-      HIP_TRY(hipMemcpy(ls->tris_d, dtris.data(), sizeof(DevTri) * dtris.size(), hipMemcpyHostToDevice));
-    ls->mesh_keys = keys;
-  }
+  const bool same_meshes = (ls->mesh_keys == keys) && ls->scene_d;
+  rc = upload_packed(ls->scene_d, ls->scene_cap, ls->sc, dobjs, dtris, same_meshes);
+  if (rc) return rc;
+  ls->mesh_keys = keys;
   if (!ls->counters) {
     HIP_TRY(hipMalloc((void**)&ls->counters, sizeof(DeviceCounters)));
     HIP_TRY(hipMemset(ls->counters, 0, sizeof(DeviceCounters)));
@@ -523,7 +588,7 @@ FrameParams legacy_params(uint32_t w, uint32_t h, const float* campos, const flo
   fp.campos = ld3(campos); fp.A = ld3(A); fp.B = ld3(B); fp.C = ld3(Cc);
   fp.nA = normalize(fp.A); fp.nB = normalize(fp.B);
   fp.lensRadius = lensRadius; fp.focalDist = focalDist;
-  fp.objs = ls->objs_d; fp.tris = ls->tris_d; fp.nobj = nobj;
+  fp.sc = ls->sc; (void)nobj;
   fp.seed_lo = (uint32_t)seed; fp.seed_hi = (uint32_t)(seed >> 32);
   fp.rng_mode = TRC_RNG_REFERENCE;
   return fp;
