@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pipeline", type=int, default=2, help="0 wavefront, 1 compacted, 2 fused (default)")
+    ap.add_argument("--pipeline", type=int, default=3, help="0 wavefront, 1 compacted, 2 fused, 3 work queue (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -161,7 +161,8 @@ def main():
         paths_per_launch = cnt["paths"] / args.steps
         flop = seg_per_launch * FLOP_PER_SEGMENT + paths_per_launch * FLOP_PER_PATH
         achieved = flop / (k_ms * 1e-3) / 1e12
-        kernel_name = {0: "k_bounce<false> (+k_raygen)", 1: "k_bounce<true> (+k_raygen)", 2: "k_fused"}[args.pipeline]
+        kernel_name = {0: "k_bounce<false> (+k_raygen)", 1: "k_bounce<true> (+k_raygen)", 2: "k_fused",
+                       3: "k_queue (+memset, k_accumulate)"}[args.pipeline]
         out = {
             "metric": "Mpath-segments/s, Cornell box 512x512 path trace (mode 2), 300 iterations",
             "value": round(value, 2),
@@ -177,7 +178,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "cornell_box_512x512_mode2_300it", "width": W, "height": H,
                        "iterations_per_gpu": ITERS, "path_depth": 5, "rng": "philox4x32-10, reference reuse",
-                       "pipeline": ["wavefront", "compacted", "fused"][args.pipeline],
+                       "pipeline": ["wavefront", "compacted", "fused", "work-queue"][args.pipeline],
                        "parallelism": f"sample-index x{world}, one RCCL film sum-reduce per step" if world > 1 else "single GPU",
                        "live_segments_per_step_per_gpu": int(seg_per_launch),
                        "segments_per_path": round(seg_per_launch / max(paths_per_launch, 1), 4)},

@@ -67,14 +67,22 @@ typedef enum trc_rng_mode { TRC_RNG_REFERENCE = 0, TRC_RNG_DECORRELATED = 1 } tr
  *                       raytrace.cu:211-225), dead paths skipped by flag;
  *  TRC_PIPE_COMPACTED   same, but live paths are compacted into a queue after every bounce by
  *                       wavefront ballot (README.md:56 "stream compaction");
- *  TRC_PIPE_FUSED       one persistent launch per call: ray state stays in registers across
- *                       bounces and iterations, finished lanes regenerate the next sample.  */
-typedef enum trc_pipeline { TRC_PIPE_WAVEFRONT = 0, TRC_PIPE_COMPACTED = 1, TRC_PIPE_FUSED = 2 } trc_pipeline;
+ *  TRC_PIPE_FUSED       one launch per call: a lane owns a pixel, ray state stays in registers
+ *                       across bounces and iterations, a finished lane regenerates that
+ *                       pixel's next sample;
+ *  TRC_PIPE_QUEUE       persistent wavefronts pull (pixel, iteration) path tasks from a global
+ *                       work queue, so lanes never idle on short paths or cheap pixels; the
+ *                       samples pass through a staging buffer in HBM and are summed per pixel
+ *                       in iteration order by a second kernel (default).                    */
+typedef enum trc_pipeline { TRC_PIPE_WAVEFRONT = 0, TRC_PIPE_COMPACTED = 1, TRC_PIPE_FUSED = 2,
+                            TRC_PIPE_QUEUE = 3 } trc_pipeline;
 
 typedef enum trc_option {
   TRC_OPT_RNG_MODE = 0,     /* trc_rng_mode, default TRC_RNG_REFERENCE */
-  TRC_OPT_PIPELINE = 1,     /* trc_pipeline, default TRC_PIPE_FUSED */
-  TRC_OPT_RECORD_HITS = 2   /* 0/1: raytrace1 also stores id/t/pos/nor per pixel (default 1) */
+  TRC_OPT_PIPELINE = 1,     /* trc_pipeline, default TRC_PIPE_QUEUE */
+  TRC_OPT_RECORD_HITS = 2,  /* 0/1: raytrace1 also stores id/t/pos/nor per pixel (default 1) */
+  TRC_OPT_STAGE_MB = 3      /* TRC_PIPE_QUEUE: staging buffer budget in MiB (default 2048); a call is
+                               split into chunks of iterations that fit */
 } trc_option;
 
 /* Device-side event counts since the last trc_reset_counters (units of SURVEY.md 8d). */

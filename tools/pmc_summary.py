@@ -1,9 +1,11 @@
 import csv, glob, json, re, sys
 out_dir, tag = sys.argv[1], sys.argv[2]
+import os
+kname = os.environ.get("KNAME", "k_queue")
 c = {}
 for f in glob.glob(out_dir + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_fused" in r["Kernel_Name"]:
+        if kname in r["Kernel_Name"]:
             c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0) + float(r["Counter_Value"])
             c["VGPR_Count"] = int(r["VGPR_Count"]); c["Accum_VGPR_Count"] = int(r["Accum_VGPR_Count"]); c["SGPR_Count"] = int(r["SGPR_Count"])
             c["Scratch_Size"] = int(r["Scratch_Size"])
@@ -17,7 +19,7 @@ d = {"kernel_ms_under_profiler": ms, "live_segments": segs,
      "valu_lane_utilisation_pct": 100 * c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64),
      "valu_insts_per_64_segments": c["SQ_INSTS_VALU"] / (segs / 64),
      "salu_insts_per_64_segments": c["SQ_INSTS_SALU"] / (segs / 64)}
-json.dump({"kernel": "trc::k_fused", "tag": tag,
+json.dump({"kernel": "trc::" + kname, "tag": tag,
            "workload": "cornell 512x512 mode 2, 300 iterations, one launch",
            "command": "tools/pmc_fused.sh (two rocprofv3 --pmc passes of python3 tools/prof_run.py 2 1)",
            "counters": c, "derived": d}, open(out_dir + "/summary.json", "w"), indent=1)

@@ -25,7 +25,7 @@ for math_mode in (1, 0):
     o.set_math_mode(math_mode)
     for rng in (0, 1):
         ref = o.pathtrace(s, W, H, ocam, 5, 1, 3, rng_mode=rng, nthreads=8)
-        for pipe in (PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED):
+        for pipe in (0, 1, 2, 3):
             tr.set_pipeline(pipe); tr.set_rng_mode(rng); tr.reset_film(); tr.reset_counters()
             tr.pathtrace(cam, 5, 1, 3)
             film = tr.read_film(); l2 = tr.read_ldr(); c = tr.counters()

@@ -6,8 +6,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RNG_REFERENCE, RNG_DECORRELATED = 0, 1
-PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED = 0, 1, 2
-OPT_RNG_MODE, OPT_PIPELINE, OPT_RECORD_HITS = 0, 1, 2
+PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED, PIPE_QUEUE = 0, 1, 2, 3
+OPT_RNG_MODE, OPT_PIPELINE, OPT_RECORD_HITS, OPT_STAGE_MB = 0, 1, 2, 3
 
 # every symbol include/tracer_abi.h declares
 ABI_SYMBOLS = [
@@ -175,6 +175,9 @@ class Tracer:
 
     def set_pipeline(self, pipe):
         self._check(self.L.trc_set_option(self.ctx, OPT_PIPELINE, pipe))
+
+    def set_stage_mb(self, mb):
+        self._check(self.L.trc_set_option(self.ctx, OPT_STAGE_MB, int(mb)))
 
     def set_record_hits(self, on):
         self._check(self.L.trc_set_option(self.ctx, OPT_RECORD_HITS, int(bool(on))))

@@ -50,6 +50,14 @@ void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compa
 void launch_fused(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
                   float* film, DeviceCounters* counters, hipStream_t stream);
 
+// mode 2, persistent work-queue pipeline: `n_iters` iterations (iter_first, +stride, ...) as
+// npix*n_iters independent path tasks pulled from a global counter by `resident_blocks`
+// persistent workgroups; per-path radiance goes through `stage` (3*npix*n_iters floats) and is
+// added to the film in iteration order by a second kernel.
+void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
+                  float* film, float* stage, uint32_t* next_task, unsigned resident_blocks,
+                  DeviceCounters* counters, hipStream_t stream);
+
 // display transform (raytrace.cu:173) over the whole film.
 void launch_tonemap(const float* film, uint32_t npix, float iters, uint32_t* ldr, hipStream_t stream);
 

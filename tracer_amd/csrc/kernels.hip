@@ -240,6 +240,95 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
   count_add(&counters->paths, valid ? (unsigned long long)n_iters : 0ull);
 }
 
+
+// ---- persistent work-queue pipeline ------------------------------------------------------------
+// The unit of scheduling is ONE PATH = (pixel, iteration). A fixed grid of persistent wavefronts
+// (as many as stay resident) pulls task ids from a global counter, kGrab at a time per wave, and
+// a lane whose path ended takes the next task at once. Every trip of the loop is therefore a
+// closest-hit for all 64 lanes of every resident wave until the queue runs dry -- no idle
+// lanes inside a wave (paths of different length) and no tail across waves (pixels of
+// different cost), whatever the image size.
+// The reference sums a pixel's samples in iteration order (raytrace.cu:170). To keep that sum
+// bit-exact although samples now finish in any order on any lane, a path that reaches the
+// light stores its radiance into a zero-initialised staging buffer stage[iteration][pixel]
+// (12 B per path; 0.94 GB for 512x512x300, nothing against 288 GB of HBM) and
+// k_accumulate adds the staged samples per pixel in iteration order afterwards.
+constexpr uint32_t kGrab = 512;
+
+__global__ __launch_bounds__(kBlock, 4) void k_queue(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
+                                                    uint32_t n_iters, float* __restrict__ stage,
+                                                    uint32_t* __restrict__ next_task, DeviceCounters* counters) {
+  const uint32_t total = fp.npix * n_iters;
+  const unsigned lane = lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: task ids this wave has reserved
+  bool exhausted = false;                    // wave-uniform: the global queue is empty
+  bool have = false;                         // this lane carries a live path
+  uint32_t pixel = 0, itk = 0, iter = 0;
+  int depth = 0;
+  Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
+  f3 col = splat3(0.0f);
+  uint32_t live = 0, tt = 0, paths = 0;
+
+  while (true) {
+    unsigned long long need = __ballot(!have);
+    while (need != 0ull && !exhausted) {
+      if (pool_next == pool_end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next_task, kGrab);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= total) { exhausted = true; break; }
+        pool_next = base;
+        pool_end = (total - base < kGrab) ? total : base + kGrab;
+      }
+      const uint32_t avail = pool_end - pool_next;
+      const uint32_t rank = __popcll(need & lt_mask);
+      if (!have && rank < avail) {
+        const uint32_t id = pool_next + rank;
+        itk = id / fp.npix;
+        pixel = id - itk * fp.npix;
+        iter = iter_first + itk * iter_stride;
+        ray = camera_sample(fp, pixel, iter);
+        col = splat3(1.0f);
+        depth = 0;
+        have = true;
+        ++paths;
+      }
+      const uint32_t wanted = __popcll(need);
+      pool_next += (wanted < avail) ? wanted : avail;
+      need = __ballot(!have);
+    }
+    if (__ballot(have) == 0ull) break;
+    const int res = bounce_step(fp, have, pixel, iter, depth, ray, col, tt);
+    if (res == STEP_CONTINUE) {
+      ++live; ++depth;
+    } else if (res != STEP_IDLE) {
+      ++live;
+      if (res == STEP_LIGHT) {                                        // black endings add nothing
+        float* dst = stage + 3ull * ((unsigned long long)itk * fp.npix + pixel);
+        dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
+      }
+      have = false;
+    }
+  }
+  count_add(&counters->live_segments, (unsigned long long)live);
+  count_add(&counters->tri_tests, (unsigned long long)tt);
+  count_add(&counters->paths, (unsigned long long)paths);
+}
+
+// film[pixel] += stage[0][pixel] + stage[1][pixel] + ... strictly in that order (raytrace.cu:170);
+// the film restarts from zero when the first staged iteration is number 1 (raytrace.cu:103-104).
+__global__ __launch_bounds__(kBlock) void k_accumulate(float* __restrict__ film, const float* __restrict__ stage,
+                                                      uint32_t npix, uint32_t n_iters, int restart) {
+  const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;   // one lane per film FLOAT: fully coalesced
+  if (idx >= 3u * npix) return;
+  float f = restart ? 0.0f : film[idx];
+  const float* s = stage + idx;
+  const size_t pitch = 3ull * npix;
+  for (uint32_t k = 0; k < n_iters; ++k) f = f + s[k * pitch];
+  film[idx] = f;
+}
+
 // ---- display transform, raytrace.cu:173 -----------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_tonemap(const float* __restrict__ film, uint32_t npix, float iters,
                                                    uint32_t* __restrict__ ldr) {
@@ -278,6 +367,20 @@ void launch_fused(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
                   float* film, DeviceCounters* counters, hipStream_t stream) {
   hipLaunchKernelGGL(k_fused, dim3(grid_for(fp.npix)), dim3(kBlock), 0, stream,
                      fp, iter_first, iter_stride, n_iters, film, counters);
+}
+
+void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
+                  float* film, float* stage, uint32_t* next_task, unsigned resident_blocks,
+                  DeviceCounters* counters, hipStream_t stream) {
+  const size_t paths = (size_t)fp.npix * n_iters;
+  (void)hipMemsetAsync(stage, 0, sizeof(float) * 3ull * paths, stream);
+  (void)hipMemsetAsync(next_task, 0, sizeof(uint32_t), stream);
+  unsigned blocks = (unsigned)((paths + kBlock - 1) / kBlock);
+  if (blocks > resident_blocks) blocks = resident_blocks;
+  hipLaunchKernelGGL(k_queue, dim3(blocks), dim3(kBlock), 0, stream,
+                     fp, iter_first, iter_stride, n_iters, stage, next_task, counters);
+  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(3u * fp.npix)), dim3(kBlock), 0, stream,
+                     film, (const float*)stage, fp.npix, n_iters, iter_first == 1u ? 1 : 0);
 }
 
 void launch_tonemap(const float* film, uint32_t npix, float iters, uint32_t* ldr, hipStream_t stream) {

@@ -46,7 +46,8 @@ struct trc_ctx {
   bool timed = false;
 
   int rng_mode = TRC_RNG_REFERENCE;
-  int pipeline = TRC_PIPE_FUSED;
+  int pipeline = TRC_PIPE_QUEUE;
+  int stage_mb = 2048;
   int record_hits = 1;
 
   // scene: one device allocation [xforms | cube extras | mesh extras | materials | triangles]
@@ -67,6 +68,11 @@ struct trc_ctx {
   float* state_mem[2] = { nullptr, nullptr };
   PathState state[2];
   uint32_t* queue_count = nullptr;
+
+  // work-queue pipeline
+  float* stage = nullptr; size_t stage_floats = 0;
+  uint32_t* next_task = nullptr;
+  unsigned resident_blocks = 0;
 
   DeviceCounters* counters = nullptr;
 };
@@ -300,7 +306,7 @@ int trc_destroy(trc_ctx* c) {
   free_dev(c->film_own); free_dev(c->ldr);
   free_dev(c->hit_id); free_dev(c->hit_t); free_dev(c->hit_pos); free_dev(c->hit_nor);
   free_dev(c->state_mem[0]); free_dev(c->state_mem[1]); free_dev(c->queue_count);
-  free_dev(c->counters);
+  free_dev(c->counters); free_dev(c->stage); free_dev(c->next_task);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -316,10 +322,13 @@ int trc_set_option(trc_ctx* c, int option, int value) {
       if (value != TRC_RNG_REFERENCE && value != TRC_RNG_DECORRELATED) return fail(TRC_ERR_INVALID, "bad rng mode");
       c->rng_mode = value; return TRC_OK;
     case TRC_OPT_PIPELINE:
-      if (value < TRC_PIPE_WAVEFRONT || value > TRC_PIPE_FUSED) return fail(TRC_ERR_INVALID, "bad pipeline");
+      if (value < TRC_PIPE_WAVEFRONT || value > TRC_PIPE_QUEUE) return fail(TRC_ERR_INVALID, "bad pipeline");
       c->pipeline = value; return TRC_OK;
     case TRC_OPT_RECORD_HITS:
       c->record_hits = value ? 1 : 0; return TRC_OK;
+    case TRC_OPT_STAGE_MB:
+      if (value < 1) return fail(TRC_ERR_INVALID, "bad staging budget");
+      c->stage_mb = value; return TRC_OK;
     default: return fail(TRC_ERR_INVALID, "unknown option");
   }
 }
@@ -381,11 +390,39 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
   HIP_TRY(hipSetDevice(c->device));
   FrameParams fp = make_params(c, cam, seed);
   const uint32_t last_iter = iter_first + (n_iters - 1) * iter_stride;
-  if (c->pipeline != TRC_PIPE_FUSED) {
+  if (c->pipeline == TRC_PIPE_WAVEFRONT || c->pipeline == TRC_PIPE_COMPACTED) {
     int rc = ensure_wavefront_state(c, c->pipeline == TRC_PIPE_COMPACTED); if (rc) return rc;
   }
+  uint32_t chunk_iters = 0;
+  if (c->pipeline == TRC_PIPE_QUEUE) {
+    // iterations per chunk: what fits the staging budget (at least one), paths per chunk < 2^31
+    const size_t per_iter = 3ull * c->npix;
+    size_t fit = ((size_t)c->stage_mb << 20) / (sizeof(float) * per_iter);
+    const size_t cap31 = 0x7FFFFFFFull / c->npix;
+    if (fit > cap31) fit = cap31;
+    if (fit < 1) fit = 1;
+    chunk_iters = (uint32_t)(fit < n_iters ? fit : n_iters);
+    const size_t need = per_iter * chunk_iters;
+    if (need > c->stage_floats) {
+      free_dev(c->stage); c->stage_floats = 0;
+      HIP_TRY(hipMalloc((void**)&c->stage, sizeof(float) * need));
+      c->stage_floats = need;
+    }
+    if (!c->next_task) HIP_TRY(hipMalloc((void**)&c->next_task, sizeof(uint32_t)));
+    if (!c->resident_blocks) {
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+      c->resident_blocks = (unsigned)prop.multiProcessorCount * 4u;   // 4 x 256 threads per CU = 4 waves per SIMD
+    }
+  }
   int rc = begin_timing(c); if (rc) return rc;
-  if (c->pipeline == TRC_PIPE_FUSED) {
+  if (c->pipeline == TRC_PIPE_QUEUE) {
+    for (uint32_t done = 0; done < n_iters; done += chunk_iters) {
+      const uint32_t n = (n_iters - done < chunk_iters) ? n_iters - done : chunk_iters;
+      launch_queue(fp, iter_first + done * iter_stride, iter_stride, n, c->film, c->stage, c->next_task,
+                   c->resident_blocks, c->counters, c->stream);
+    }
+  } else if (c->pipeline == TRC_PIPE_FUSED) {
     launch_fused(fp, iter_first, iter_stride, n_iters, c->film, c->counters, c->stream);
   } else {
     const bool compact = c->pipeline == TRC_PIPE_COMPACTED;
