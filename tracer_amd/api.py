@@ -50,7 +50,8 @@ class Counters(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libtracer_amd.so")
+    # TRC_LIB: load another build of the same library (kernel tuning experiments)
+    return os.environ.get("TRC_LIB") or os.path.join(_HERE, "libtracer_amd.so")
 
 
 _lib = None

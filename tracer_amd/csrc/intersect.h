@@ -37,25 +37,70 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+
+// ---- short correctly-rounded 1/sqrt and reciprocal -------------------------------------------------
+// glm::normalize is v * (1 / sqrt(s)) with BOTH the square root and the division correctly rounded
+// (func_geometric.inl:243, func_exponential.inl:151); hipcc's IEEE sqrtf + division cost 28 VALU
+// instructions, most of them range scaling and special-case fix-ups. The sequences below were
+// compared with those IEEE results for ALL 2^32 inputs on gfx950 (tools/micro/crmath_check.hip):
+//   sqrt:  v_sqrt, v_rsq, one fma residual, one fma correction -- exact for every x >= 2^-102
+//   1/x :  v_rcp + one Newton step                             -- exact for every normal |x| < 2^126
+// Outside those ranges (zero vectors, denormals, inf, NaN) the wave takes the IEEE path; the
+// choice is made per wavefront with a ballot, so the result is bit-identical either way.
+// `need` = this lane's result is observable (dead / masked lanes must not force the slow path).
+__device__ __forceinline__ float cr_rsqrt(float s, bool need) {
+  const bool ok = (__float_as_uint(s) - 0x0D000000u) < (0x7E800000u - 0x0D000000u);   // 2^-101 <= s < 2^126
+  if (__ballot(need & !ok) == 0ull) {
+    const float q0 = __builtin_amdgcn_sqrtf(s);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
+    const float q = __builtin_fmaf(__builtin_fmaf(-q0, q0, s), h, q0);      // correctly rounded sqrt(s)
+    const float r0 = __builtin_amdgcn_rcpf(q);
+    return __builtin_fmaf(__builtin_fmaf(-q, r0, 1.0f), r0, r0);            // correctly rounded 1/q
+  }
+  return 1.0f / sqrtf(s);
+}
+__device__ __forceinline__ float cr_sqrt(float s, bool need) {
+  const bool ok = (__float_as_uint(s) - 0x0D000000u) < (0x7F800000u - 0x0D000000u);   // 2^-101 <= s < inf
+  if (__ballot(need & !ok) == 0ull) {
+    const float q0 = __builtin_amdgcn_sqrtf(s);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
+    return __builtin_fmaf(__builtin_fmaf(-q0, q0, s), h, q0);
+  }
+  return sqrtf(s);
+}
+__device__ __forceinline__ float cr_rcp(float x, bool need) {
+  const bool ok = ((__float_as_uint(x) & 0x7FFFFFFFu) - 0x00800000u) < (0x7E800000u - 0x00800000u); // normal, |x| < 2^126
+  if (__ballot(need & !ok) == 0ull) {
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+  }
+  return 1.0f / x;
+}
+// glm::normalize (func_geometric.inl:243-244) on the device
+__device__ __forceinline__ f3 normalize_dev(f3 v, bool need) {
+  const float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
+  return v * cr_rsqrt(sqr, need);
+}
+
 __device__ __forceinline__ Hit no_hit() {   // Ray.inl:30  Hit() : m_t(-1), m_id(-1), vec3s zero
   Hit h; h.t = -1.0f; h.id = -1; h.pos = splat3(0.0f); h.nor = splat3(0.0f); return h;
 }
 
 // Ray.inl:50-57: two point transforms, direction RE-normalised in object space
-__device__ __forceinline__ Ray to_object_space(const Ray& ray, const Affine& mi) {
+__device__ __forceinline__ Ray to_object_space(const Ray& ray, const Affine& mi, bool live) {
   f3 pos = xform_point(mi, ray.pos);
   f3 point = xform_point(mi, ray.pos + ray.dir);
-  Ray r; r.pos = pos; r.dir = normalize(point - pos);
+  Ray r; r.pos = pos; r.dir = normalize_dev(point - pos, live);
   return r;
 }
 
 // Ray.inl:189-226 Moeller-Trumbore with barycentric normal interpolation and back-face cull.
 // Returns t (or -1 for "no hit", the m_t of a default Hit) and the un-normalised normal.
-__device__ __forceinline__ float hit_triangle(const Ray& ray, const DevTri& tri, f3& nor) {
+__device__ __forceinline__ float hit_triangle(const Ray& ray, const DevTri& tri, f3& nor, bool need = true) {
   f3 pvec = cross(ray.dir, tri.e2);
   float det = dot(tri.e1, pvec);
   if (gabs(det) < kEps) return -1.0f;
-  det = 1.0f / det;
+  det = cr_rcp(det, need);
   f3 tvec = ray.pos - tri.v0;
   float bx = dot(tvec, pvec) * det;
   if (bx < 0.0f || bx > 1.0f) return -1.0f;
@@ -111,7 +156,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, bool pass, const Dev
         rr.dir = mk3(read_lane(r.dir.x, L), read_lane(r.dir.y, L), read_lane(r.dir.z, L));
         const float bestL = read_lane(best, L);
         f3 n = splat3(0.0f);
-        const float t = hit_triangle(rr, tri, n);
+        const float t = hit_triangle(rr, tri, n, valid);
         // Ray.inl:174  thit.m_t > 0 && thit.m_t < hit.m_t ; positive floats order as their bits
         const unsigned cand = (valid && t > 0.0f && t < bestL) ? __float_as_uint(t) : INF_BITS;
         const unsigned tmin = wave_umin(cand);
@@ -154,10 +199,10 @@ __device__ __forceinline__ void consider(Closest& c, const Ray& ray, float t, ui
 // K planes at once, branch-free. Ray.inl:142-158: t = -o.y/d.y, hit iff |x|,|z| < 0.5 (strict);
 // the normal is always object +y -> DevXform::nor_y.
 template <int K>
-__device__ __forceinline__ void planes(Closest& c, const Ray& ray, const DevXform* __restrict__ xf) {
+__device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf) {
   Ray r[K]; float t[K]; f3 p[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[k].mi);          // Ray.inl:88
+  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[k].mi, live);    // Ray.inl:88
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const float tp = -r[k].pos.y / r[k].dir.y;
@@ -172,22 +217,23 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, const DevXfor
 // K spheres at once. Ray.inl:103-118: radius 0.5, geometric method, normal = normalize(pos),
 // then Ray.inl:62 normalize(M * (n, 0)).
 template <int K>
-__device__ __forceinline__ void spheres(Closest& c, const Ray& ray, const DevXform* __restrict__ xf) {
+__device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf) {
   Ray r[K]; float t[K]; f3 p[K], wn[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[k].mi);
+  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[k].mi, live);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const f3 l = -r[k].pos;
     const float s = dot(l, r[k].dir);
     const float l2 = dot(l, l);
     const float m2 = l2 - s * s;
-    const bool hit = !((s < 0.0f) & (l2 > 0.25f)) & !(m2 > 0.25f);
-    const float q = sqrtf(0.25f - m2);
+    const bool hit = live & !((s < 0.0f) & (l2 > 0.25f)) & !(m2 > 0.25f);
+    const float q = cr_sqrt(0.25f - m2, hit);
     const float th = (l2 > 0.25f) ? s - q : s + q;
     t[k] = hit ? th : -1.0f;
     p[k] = r[k].pos + r[k].dir * th;
-    wn[k] = normalize(xform_dir(xf[k].m, normalize(p[k])));
+    const bool use = hit & (th > 0.0f);                        // only a competing hit's normal is observable
+    wn[k] = normalize_dev(xform_dir(xf[k].m, normalize_dev(p[k], use)), use);
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) consider(c, ray, t[k], xf[k].id, xf[k].m, p[k], wn[k]);
@@ -195,8 +241,8 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, const DevXfo
 
 // Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
 // -x,+x,-y,+y,-z,else +z, taken from the per-object table of world normals.
-__device__ __forceinline__ void cube(Closest& c, const Ray& ray, const DevXform& xf, const DevCubeExtra& ex) {
-  const Ray r = to_object_space(ray, xf.mi);
+__device__ __forceinline__ void cube(Closest& c, const Ray& ray, bool live, const DevXform& xf, const DevCubeExtra& ex) {
+  const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
   const bool hit = slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar);
   const float th = tNear > 0.0f ? tNear : tFar;
@@ -214,7 +260,7 @@ __device__ __forceinline__ void cube(Closest& c, const Ray& ray, const DevXform&
 // Ray.inl:160-186 (MESH): AABB slab test, then mesh_closest().
 __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, const DevXform& xf,
                                      const DevMeshExtra& ex, const DevTri* __restrict__ tris, uint32_t& tri_tests) {
-  const Ray r = to_object_space(ray, xf.mi);
+  const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
   const bool pass = live && slab(r, ex.bmin, ex.bmax, tNear, tFar);
   f3 bn;
@@ -224,7 +270,7 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, cons
   // to inf for any normalised d -> explicit miss here.
   const bool hit = pass && tb != FLT_MAX;
   const f3 p = r.pos + r.dir * tb;
-  const f3 wn = normalize(xform_dir(xf.m, bn));               // Ray.inl:62
+  const f3 wn = normalize_dev(xform_dir(xf.m, bn), hit);      // Ray.inl:62
   consider(c, ray, hit ? tb : -1.0f, xf.id, xf.m, p, wn);
 }
 
@@ -233,13 +279,13 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevS
   Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
   const DevXform* __restrict__ xf = sc.xf;
   uint32_t i = 0;
-  for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, xf + i);
-  if (i < sc.n_plane) planes<1>(c, ray, xf + i);
+  for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, live, xf + i);
+  if (i < sc.n_plane) planes<1>(c, ray, live, xf + i);
   xf += sc.n_plane;
-  for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, xf + i);
-  if (i < sc.n_sphere) spheres<1>(c, ray, xf + i);
+  for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, live, xf + i);
+  if (i < sc.n_sphere) spheres<1>(c, ray, live, xf + i);
   xf += sc.n_sphere;
-  for (i = 0; i < sc.n_cube; ++i) cube(c, ray, xf[i], sc.cubes[i]);
+  for (i = 0; i < sc.n_cube; ++i) cube(c, ray, live, xf[i], sc.cubes[i]);
   xf += sc.n_cube;
   for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc.tris, tri_tests);
   Hit h; h.t = c.t; h.id = c.id; h.pos = c.pos; h.nor = c.nor;

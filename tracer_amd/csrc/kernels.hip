@@ -43,7 +43,7 @@ __device__ __forceinline__ Ray primary_ray(const FrameParams& fp, uint32_t idx) 
 
 // initBuffersKernel, raytrace.cu:72-96: +-1 pixel jitter and thin-lens depth of field, all
 // from the one triple rand[idx] (x, y reused by jitter and lens).
-__device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx, uint32_t iter) {
+__device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx, uint32_t iter, bool need = true) {
   uint32_t x = idx % fp.w;
   uint32_t y = idx / fp.w;
   f3 r = rand3(fp.seed_lo, fp.seed_hi, idx, iter, 0u);
@@ -51,12 +51,12 @@ __device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx
   float v = (float)y / fp.h + (2.0f * r.y - 1.0f) / fp.h;
   Ray ray;
   ray.pos = fp.campos + fp.C + (2.0f * u - 1.0f) * fp.A + (2.0f * v - 1.0f) * fp.B;
-  ray.dir = normalize(ray.pos - fp.campos);
+  ray.dir = normalize_dev(ray.pos - fp.campos, need);
   f3 fpt = fp.focalDist * ray.dir + ray.pos;
   f2 disk = rand_point_disk(r.x, r.y, r.z);
   float dkx = fp.lensRadius * disk.x, dky = fp.lensRadius * disk.y;
   ray.pos = ray.pos + (dky * fp.nA + dkx * fp.nB);          // note the x/y swap, raytrace.cu:94
-  ray.dir = normalize(fpt - ray.pos);
+  ray.dir = normalize_dev(fpt - ray.pos, need);
   return ray;
 }
 
@@ -254,8 +254,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
 // (12 B per path; 0.94 GB for 512x512x300, nothing against 288 GB of HBM) and
 // k_accumulate adds the staged samples per pixel in iteration order afterwards.
 constexpr uint32_t kGrab = 512;
+#ifndef TRC_QUEUE_WAVES
+#define TRC_QUEUE_WAVES 4          // resident waves per SIMD the kernel is compiled for
+#endif
 
-__global__ __launch_bounds__(kBlock, 4) void k_queue(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
+__global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                     uint32_t n_iters, float* __restrict__ stage,
                                                     uint32_t* __restrict__ next_task, DeviceCounters* counters) {
   const uint32_t total = fp.npix * n_iters;
@@ -376,6 +379,7 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
   (void)hipMemsetAsync(stage, 0, sizeof(float) * 3ull * paths, stream);
   (void)hipMemsetAsync(next_task, 0, sizeof(uint32_t), stream);
   unsigned blocks = (unsigned)((paths + kBlock - 1) / kBlock);
+  resident_blocks = resident_blocks / 4u * TRC_QUEUE_WAVES;     // CUs x waves per SIMD (a block = 1 wave per SIMD)
   if (blocks > resident_blocks) blocks = resident_blocks;
   hipLaunchKernelGGL(k_queue, dim3(blocks), dim3(kBlock), 0, stream,
                      fp, iter_first, iter_stride, n_iters, stage, next_task, counters);
