@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
 // k_accumulate adds the staged samples per pixel in iteration order afterwards.
 constexpr uint32_t kGrab = 512;
 #ifndef TRC_QUEUE_WAVES
-#define TRC_QUEUE_WAVES 4          // resident waves per SIMD the kernel is compiled for
+#define TRC_QUEUE_WAVES 5          // resident waves per SIMD the kernel is compiled for
 #endif
 
 __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
