@@ -126,46 +126,97 @@ __device__ __forceinline__ bool slab(const Ray& ray, f3 bmin, f3 bmax, float& tN
   return !(tNear > tFar || tFar < 0.0f);
 }
 
+// Branch-free Moeller-Trumbore for the cooperative test: same arithmetic as hit_triangle(), every
+// rejection folded into one predicate (the rejected lanes' values are never observed).
+__device__ __forceinline__ bool hit_triangle_all(const Ray& ray, const DevTri& tri, bool valid, float& t, f3& nor) {
+  const f3 pvec = cross(ray.dir, tri.e2);
+  const float det = dot(tri.e1, pvec);
+  bool ok = valid & !(gabs(det) < kEps);
+  const float inv = cr_rcp(det, ok);
+  const f3 tvec = ray.pos - tri.v0;
+  const float bx = dot(tvec, pvec) * inv;
+  ok &= !((bx < 0.0f) | (bx > 1.0f));
+  const f3 qvec = cross(tvec, tri.e1);
+  const float by = dot(ray.dir, qvec) * inv;
+  ok &= !((by < 0.0f) | ((bx + by) > 1.0f));
+  t = dot(tri.e2, qvec) * inv;
+  const float bz = 1.0f - bx - by;
+  nor = tri.n0 * bz + tri.n1 * bx + tri.n2 * by;
+  ok &= !(dot(ray.dir, nor) > 0);
+  return ok;
+}
+
+// Per-wave LDS mailboxes of the cooperative mesh test: one slot per passing ray.
+struct alignas(16) MeshSlot {
+  float px, py, pz, dx;            // ray (object space)
+  float dy, dz; uint32_t pad0, pad1;
+  unsigned long long key;          // (bits of t) << 32 | face index : u64 min = closest t, lowest face on ties
+  float nx, ny;
+  float nz; uint32_t pad2, pad3, pad4;
+};
+static_assert(sizeof(MeshSlot) == 64, "MeshSlot");
+constexpr int kMaxWavesPerBlock = 4;
+
 // MESH, Ray.inl:160-186: brute force over the object's triangles in face order, strict `<`
 // (lowest face index wins ties, Ray.inl:174). Wave-convergent; `pass` marks the lanes whose
 // ray passed the AABB. Returns the closest positive t (FLT_MAX if none) and its normal.
+//
+// The few passing rays of a wavefront become wave-wide work: they are compacted into LDS slots,
+// and the 64 lanes enumerate (ray, triangle) PAIRS -- a mesh of G < 64 triangles takes 64/G rays per
+// pass (the 20-triangle icosahedron: 3 rays on 60 lanes), larger meshes one ray per 64-triangle
+// chunk. Every hit does one ds_min_u64 on its ray's key; the winner then leaves its normal in the
+// slot and the ray's own lane collects (t, normal) at the end.
 __device__ __forceinline__ float mesh_closest(const Ray& r, bool pass, const DevTri* __restrict__ tris,
-                                              uint32_t first, uint32_t count, f3& bn, uint32_t& tri_tests) {
+                                              const DevMeshExtra& ex, f3& bn, uint32_t& tri_tests) {
+  __shared__ MeshSlot s_slots[kMaxWavesPerBlock * 64];
+  const uint32_t first = ex.tri_first, count = ex.tri_count;
   float best = FLT_MAX;
   bn = splat3(0.0f);
   const unsigned long long mask = __ballot(pass);
   if (mask == 0ull || count == 0u) return best;
   const unsigned n_pass = __popcll(mask);
-  const unsigned n_chunks = (count + 63u) >> 6;
   if (pass) tri_tests += count;
-  // cost model (VALU instructions per wave): triangle-per-lane ~ n_pass * n_chunks * 130,
+  const unsigned lane = lane_id();
+  const unsigned G = count < 64u ? count : 64u;                  // triangles side by side in one pass
+  const unsigned R = ex.rays_per_pass;                           // 64 / G rays side by side
+  const unsigned n_chunks = (count + 63u) >> 6;
+  // cost model (VALU instructions per wave): pair enumeration ~ ceil(n_pass / R) * n_chunks * 110,
   // ray-per-lane ~ count * 95
-  if (n_pass * n_chunks * 4u <= count * 3u) {
-    const unsigned lane = lane_id();
-    const unsigned INF_BITS = 0x7f800000u;
+  if (((n_pass + R - 1u) / R) * n_chunks * 5u <= count * 4u) {
+    MeshSlot* __restrict__ slots = s_slots + (threadIdx.x >> 6) * 64;
+    const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const unsigned long long KEY_NONE = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // t = FLT_MAX
+    if (pass) {
+      MeshSlot& m = slots[rank];
+      m.px = r.pos.x; m.py = r.pos.y; m.pz = r.pos.z; m.dx = r.dir.x; m.dy = r.dir.y; m.dz = r.dir.z;
+      m.key = KEY_NONE;
+    }
+    const unsigned sub = (lane * ex.group_magic) >> 16;         // lane / G
+    const unsigned tl = lane - sub * G;                         // lane % G
+    const bool lane_used = sub < R;
     for (uint32_t base = 0; base < count; base += 64u) {
-      const uint32_t ti = base + lane;
-      const bool valid = ti < count;
-      const DevTri tri = tris[first + (valid ? ti : count - 1u)];
-      unsigned long long m = mask;
-      while (m) {                                              // one passing ray at a time
-        const int L = __builtin_ctzll(m);
-        m &= m - 1ull;
+      const uint32_t ti = base + tl;
+      const bool tvalid = lane_used & (ti < count);
+      const DevTri tri = tris[first + (tvalid ? ti : 0u)];
+      for (unsigned s0 = 0; s0 < n_pass; s0 += R) {
+        const unsigned slot = s0 + sub;
+        const bool valid = tvalid & (slot < n_pass);
+        MeshSlot& m = slots[valid ? slot : 0u];
         Ray rr;
-        rr.pos = mk3(read_lane(r.pos.x, L), read_lane(r.pos.y, L), read_lane(r.pos.z, L));
-        rr.dir = mk3(read_lane(r.dir.x, L), read_lane(r.dir.y, L), read_lane(r.dir.z, L));
-        const float bestL = read_lane(best, L);
-        f3 n = splat3(0.0f);
-        const float t = hit_triangle(rr, tri, n, valid);
-        // Ray.inl:174  thit.m_t > 0 && thit.m_t < hit.m_t ; positive floats order as their bits
-        const unsigned cand = (valid && t > 0.0f && t < bestL) ? __float_as_uint(t) : INF_BITS;
-        const unsigned tmin = wave_umin(cand);
-        if (tmin != INF_BITS) {
-          const int win = __builtin_ctzll(__ballot(cand == tmin));   // lowest lane = lowest face index
-          const float nx = read_lane(n.x, win), ny = read_lane(n.y, win), nz = read_lane(n.z, win);
-          if (lane == (unsigned)L) { best = __uint_as_float(tmin); bn = mk3(nx, ny, nz); }
-        }
+        rr.pos = mk3(m.px, m.py, m.pz); rr.dir = mk3(m.dx, m.dy, m.dz);
+        float t; f3 n;
+        const bool hit = hit_triangle_all(rr, tri, valid, t, n);
+        // Ray.inl:174  thit.m_t > 0 && thit.m_t < hit.m_t (initially FLT_MAX); positive floats order as their bits
+        const bool cand = hit & (t > 0.0f) & (t < FLT_MAX);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | ti;
+        if (cand) atomicMin(&m.key, key);
+        if (cand && m.key == key) { m.nx = n.x; m.ny = n.y; m.nz = n.z; }
       }
+    }
+    if (pass) {
+      const MeshSlot& m = slots[rank];
+      best = __uint_as_float((unsigned)(m.key >> 32));
+      if (best != FLT_MAX) bn = mk3(m.nx, m.ny, m.nz);
     }
   } else if (pass) {
     for (uint32_t i = 0; i < count; ++i) {
@@ -264,7 +315,7 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, cons
   float tNear, tFar;
   const bool pass = live && slab(r, ex.bmin, ex.bmax, tNear, tFar);
   f3 bn;
-  const float tb = mesh_closest(r, pass, tris, ex.tri_first, ex.tri_count, bn, tri_tests);
+  const float tb = mesh_closest(r, pass, tris, ex, bn, tri_tests);
   // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero normal
   // forward; the world-space distance test then rejects it because |o + d*FLT_MAX|^2 overflows
   // to inf for any normalised d -> explicit miss here.

@@ -73,9 +73,14 @@ struct alignas(16) DevXform {      // 128 bytes = two s_load_dwordx16
 };
 static_assert(sizeof(DevXform) == 128, "DevXform");
 struct alignas(16) DevCubeExtra { f3 axis_nor[6]; float pad[2]; };                 // 80 bytes
-struct alignas(16) DevMeshExtra { f3 bmin; uint32_t tri_first; f3 bmax; uint32_t tri_count; };
+struct alignas(16) DevMeshExtra {
+  f3 bmin; uint32_t tri_first; f3 bmax; uint32_t tri_count;
+  // cooperative test (intersect.h): G = min(tri_count, 64) triangles side by side, 64 / G rays per pass;
+  // lane / G == (lane * group_magic) >> 16 for lane < 64
+  uint32_t group_magic, rays_per_pass, pad0, pad1;
+};
 struct alignas(16) DevMaterial  { f3 color; float emit; float brdf; float ior; int32_t mat_type; int32_t pad; };
-static_assert(sizeof(DevCubeExtra) == 80 && sizeof(DevMeshExtra) == 32 && sizeof(DevMaterial) == 32, "extras");
+static_assert(sizeof(DevCubeExtra) == 80 && sizeof(DevMeshExtra) == 48 && sizeof(DevMaterial) == 32, "extras");
 
 struct DevTri;
 // Pointers into ONE device allocation holding the packed scene.

@@ -199,6 +199,8 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
         cubes.push_back(e);
       } else if (o.mesh_type == REF_MESH) {
         DevMeshExtra e; e.bmin = o.bmin; e.tri_first = o.tri_first; e.bmax = o.bmax; e.tri_count = o.tri_count;
+        const uint32_t G = o.tri_count < 64u ? (o.tri_count ? o.tri_count : 1u) : 64u;
+        e.group_magic = 65535u / G + 1u; e.rays_per_pass = 64u / G; e.pad0 = e.pad1 = 0;
         meshes.push_back(e);
       }
     }
