@@ -67,3 +67,16 @@ def test_portable_vs_libm_radiance(oracle_c):
     finally:
         oracle_c.set_math_mode(Oracle.MATH_LIBM)
     assert bad / total < 1e-3, (bad, total)
+
+
+def test_division_shortcuts_match_ieee_operators():
+    """div_by_uniform / udivmod of tracer_amd/csrc/pmath.h (used by the camera-ray and task-decoding
+    code of the kernels) against plain `/` and `%`: every pixel coordinate of 30 image widths, 2^24
+    random (width, coordinate, jitter) triples, 2^24 random + edge-case integer divisions."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "bin", "mathcheck")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp/bin/mathcheck not built (run __graft_entry__.build())")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 mismatches; udivmod" in r.stdout and r.stdout.rstrip().endswith(" 0 mismatches")

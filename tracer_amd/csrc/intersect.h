@@ -12,6 +12,12 @@
 
 #pragma clang fp contract(off)
 
+#ifdef TRC_MARKERS
+#define TRC_MARK(name) asm volatile("; MARK " name)
+#else
+#define TRC_MARK(name)
+#endif
+
 namespace trc {
 
 // ---- wave64 helpers ---------------------------------------------------------------------------
@@ -199,6 +205,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, bool pass, const Dev
       const bool tvalid = lane_used & (ti < count);
       const DevTri tri = tris[first + (tvalid ? ti : 0u)];
       for (unsigned s0 = 0; s0 < n_pass; s0 += R) {
+        TRC_MARK("mesh_pass");
         const unsigned slot = s0 + sub;
         const bool valid = tvalid & (slot < n_pass);
         MeshSlot& m = slots[valid ? slot : 0u];
@@ -211,6 +218,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, bool pass, const Dev
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | ti;
         if (cand) atomicMin(&m.key, key);
         if (cand && m.key == key) { m.nx = n.x; m.ny = n.y; m.nz = n.z; }
+        TRC_MARK("mesh_pass_end");
       }
     }
     if (pass) {
@@ -330,15 +338,20 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevS
   Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
   const DevXform* __restrict__ xf = sc.xf;
   uint32_t i = 0;
+  TRC_MARK("planes");
   for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, live, xf + i);
   if (i < sc.n_plane) planes<1>(c, ray, live, xf + i);
   xf += sc.n_plane;
+  TRC_MARK("spheres");
   for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, live, xf + i);
   if (i < sc.n_sphere) spheres<1>(c, ray, live, xf + i);
   xf += sc.n_sphere;
+  TRC_MARK("cubes");
   for (i = 0; i < sc.n_cube; ++i) cube(c, ray, live, xf[i], sc.cubes[i]);
   xf += sc.n_cube;
+  TRC_MARK("meshes");
   for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc.tris, tri_tests);
+  TRC_MARK("closest_done");
   Hit h; h.t = c.t; h.id = c.id; h.pos = c.pos; h.nor = c.nor;
   return h;
 }

@@ -2,6 +2,7 @@
 // gfx950 kernels (kernels.hip).
 #pragma once
 #include "scene.h"
+#include "pmath.h"
 #include <hip/hip_runtime.h>
 
 namespace trc {
@@ -10,6 +11,8 @@ namespace trc {
 // segment -> SGPRs).
 struct FrameParams {
   uint32_t w, h, npix;
+  UDiv div_w, div_npix;     // index -> (x, y), task -> (iteration, pixel) without an integer division
+  float fw, fh, rcp_w, rcp_h;   // (float)w, (float)h and their correctly rounded reciprocals (div_by_uniform)
   f3 campos, A, B, C;       // raytrace.cu:192
   f3 nA, nB;                // normalize(A), normalize(B) of raytrace.cu:94, hoisted to the host
   float lensRadius, focalDist;
@@ -17,6 +20,12 @@ struct FrameParams {
   uint32_t seed_lo, seed_hi;
   int rng_mode;             // trc_rng_mode
 };
+
+inline void set_dims(FrameParams& fp, uint32_t w, uint32_t h) {
+  fp.w = w; fp.h = h; fp.npix = w * h;
+  fp.div_w = make_udiv(w); fp.div_npix = make_udiv(fp.npix);
+  fp.fw = (float)w; fp.fh = (float)h; fp.rcp_w = 1.0f / fp.fw; fp.rcp_h = 1.0f / fp.fh;
+}
 
 // Per-path state of the wavefront pipelines, planar (one float per lane per plane, so every
 // load/store instruction of a wavefront covers 256 contiguous bytes). Two of these are

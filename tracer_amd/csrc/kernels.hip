@@ -32,8 +32,8 @@ __device__ __forceinline__ void count_add(unsigned long long* dst, unsigned long
 // ---- camera rays ------------------------------------------------------------------------------
 // raytrace.cu:40-43 (mode 1: pixel corner, no jitter, pinhole)
 __device__ __forceinline__ Ray primary_ray(const FrameParams& fp, uint32_t idx) {
-  uint32_t x = idx % fp.w;
-  uint32_t y = idx / fp.w;
+  uint32_t x;
+  const uint32_t y = udivmod(idx, fp.div_w, x);
   float u = (float)x / fp.w, v = (float)y / fp.h;
   Ray ray;
   ray.pos = fp.campos + fp.C + (2.0f * u - 1.0f) * fp.A + (2.0f * v - 1.0f) * fp.B;
@@ -44,11 +44,12 @@ __device__ __forceinline__ Ray primary_ray(const FrameParams& fp, uint32_t idx) 
 // initBuffersKernel, raytrace.cu:72-96: +-1 pixel jitter and thin-lens depth of field, all
 // from the one triple rand[idx] (x, y reused by jitter and lens).
 __device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx, uint32_t iter, bool need = true) {
-  uint32_t x = idx % fp.w;
-  uint32_t y = idx / fp.w;
+  uint32_t x;
+  const uint32_t y = udivmod(idx, fp.div_w, x);
   f3 r = rand3(fp.seed_lo, fp.seed_hi, idx, iter, 0u);
-  float u = (float)x / fp.w + (2.0f * r.x - 1.0f) / fp.w;
-  float v = (float)y / fp.h + (2.0f * r.y - 1.0f) / fp.h;
+  // raytrace.cu:80-81; x, y < 2^24 and |2r - 1| in {0} u [2^-24, 1]: div_by_uniform's precondition
+  float u = div_by_uniform((float)x, fp.fw, fp.rcp_w) + div_by_uniform(2.0f * r.x - 1.0f, fp.fw, fp.rcp_w);
+  float v = div_by_uniform((float)y, fp.fh, fp.rcp_h) + div_by_uniform(2.0f * r.y - 1.0f, fp.fh, fp.rcp_h);
   Ray ray;
   ray.pos = fp.campos + fp.C + (2.0f * u - 1.0f) * fp.A + (2.0f * v - 1.0f) * fp.B;
   ray.dir = normalize_dev(ray.pos - fp.campos, need);
@@ -79,7 +80,8 @@ __device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uin
   f3 rnd;
   if (fp.rng_mode == 0) {
     // :155 -- unsigned wrap-around of idx + (int)dot, then % size; ray is the PRE-bounce ray
-    uint32_t randidx = (pixel + (uint32_t)(int)dot(ray.dir, ray.pos)) % fp.npix;
+    uint32_t randidx;
+    udivmod(pixel + (uint32_t)(int)dot(ray.dir, ray.pos), fp.div_npix, randidx);
     rnd = rand3(fp.seed_lo, fp.seed_hi, randidx, iter, 0u);
   } else {
     rnd = rand3(fp.seed_lo, fp.seed_hi, pixel, iter, 1u + (uint32_t)depth);
@@ -287,15 +289,16 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
       const uint32_t avail = pool_end - pool_next;
       const uint32_t rank = __popcll(need & lt_mask);
       if (!have && rank < avail) {
+        TRC_MARK("regen");
         const uint32_t id = pool_next + rank;
-        itk = id / fp.npix;
-        pixel = id - itk * fp.npix;
+        itk = udivmod(id, fp.div_npix, pixel);
         iter = iter_first + itk * iter_stride;
         ray = camera_sample(fp, pixel, iter);
         col = splat3(1.0f);
         depth = 0;
         have = true;
         ++paths;
+        TRC_MARK("regen_end");
       }
       const uint32_t wanted = __popcll(need);
       pool_next += (wanted < avail) ? wanted : avail;
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
     }
     if (__ballot(have) == 0ull) break;
     const int res = bounce_step(fp, have, pixel, iter, depth, ray, col, tt);
+    TRC_MARK("bounce_done");
     if (res == STEP_CONTINUE) {
       ++live; ++depth;
     } else if (res != STEP_IDLE) {

@@ -17,6 +17,40 @@
 
 namespace trc {
 
+// ---- division by a wave-uniform divisor --------------------------------------------------------
+// a / d, correctly rounded, from rd = RN(1/d) (computed once on the host): the quotient estimate and
+// the two fma residual corrections of the usual IEEE expansion (what hipcc emits between its
+// v_div_scale and v_div_fixup steps), valid when nothing needs rescaling:
+//   a == 0 or 2^-60 <= |a| <= 2^60,  2^-60 <= |d| <= 2^60.
+// The camera code divides pixel coordinates (integers below 2^24) and 2r-1 with r a multiple of
+// 2^-25 in (0, 1] by the image width / height, so the precondition holds by construction there.
+// Checked against `/` for every x < w of many widths and 2^26 random numerators (tests/cpp/mathcheck).
+TRC_HD float div_by_uniform(float a, float d, float rd) {
+  float q = a * rd;
+  q = fmaf(fmaf(-d, q, a), rd, q);
+  return fmaf(fmaf(-d, q, a), rd, q);
+}
+
+// n / d and n % d for a wave-uniform d from magic = floor((2^32 - 1) / d): the high product
+// undershoots the quotient by at most 2, fixed by two conditional subtractions.
+struct UDiv { uint32_t d, magic; };
+TRC_HD UDiv make_udiv(uint32_t d) { UDiv u; u.d = d; u.magic = d ? 0xFFFFFFFFu / d : 0u; return u; }
+TRC_HD uint32_t umulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return (uint32_t)(((unsigned long long)a * b) >> 32);
+#endif
+}
+TRC_HD uint32_t udivmod(uint32_t n, UDiv u, uint32_t& rem) {
+  uint32_t q = umulhi32(n, u.magic);
+  uint32_t r = n - q * u.d;
+  if (r >= u.d) { r -= u.d; ++q; }
+  if (r >= u.d) { r -= u.d; ++q; }
+  rem = r;
+  return q;
+}
+
 // sin and cos of x (callers pass [0, 2*pi]; accuracy holds to |x| ~ 1e4)
 TRC_HD void pm_sincosf(float x, float& sn, float& cs) {
   // Cody-Waite reduction by pi/2 in three parts

@@ -112,7 +112,7 @@ void affine_from_mat4(Affine& a, const float m[16]) {
 
 FrameParams make_params(const trc_ctx* c, const trc_camera* cam, uint64_t seed) {
   FrameParams fp;
-  fp.w = c->w; fp.h = c->h; fp.npix = c->npix;
+  set_dims(fp, c->w, c->h);
   fp.campos = ld3(cam->campos); fp.A = ld3(cam->A); fp.B = ld3(cam->B); fp.C = ld3(cam->C);
   fp.nA = normalize(fp.A);       // raytrace.cu:94 evaluates these per thread; same IEEE ops here
   fp.nB = normalize(fp.B);
@@ -623,7 +623,7 @@ FrameParams legacy_params(uint32_t w, uint32_t h, const float* campos, const flo
                           const float* Cc, float lensRadius, float focalDist, const LegacyScene* ls,
                           uint32_t nobj, uint64_t seed) {
   FrameParams fp;
-  fp.w = w; fp.h = h; fp.npix = w * h;
+  set_dims(fp, w, h);
   fp.campos = ld3(campos); fp.A = ld3(A); fp.B = ld3(B); fp.C = ld3(Cc);
   fp.nA = normalize(fp.A); fp.nB = normalize(fp.B);
   fp.lensRadius = lensRadius; fp.focalDist = focalDist;
