@@ -155,12 +155,11 @@ __device__ __forceinline__ bool hit_triangle_all(const Ray& ray, const DevTri& t
 // Per-wave LDS mailboxes of the cooperative mesh test: one slot per passing ray.
 struct alignas(16) MeshSlot {
   float px, py, pz, dx;            // ray (object space)
-  float dy, dz; uint32_t pad0, pad1;
+  float dy, dz;
   unsigned long long key;          // (bits of t) << 32 | face index : u64 min = closest t, lowest face on ties
-  float nx, ny;
-  float nz; uint32_t pad2, pad3, pad4;
+  float nx, ny, nz; uint32_t pad;  // the winner's un-normalised normal
 };
-static_assert(sizeof(MeshSlot) == 64, "MeshSlot");
+static_assert(sizeof(MeshSlot) == 48, "MeshSlot");
 constexpr int kMaxWavesPerBlock = 4;
 
 // MESH, Ray.inl:160-186: brute force over the object's triangles in face order, strict `<`

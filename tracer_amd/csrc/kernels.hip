@@ -256,6 +256,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
 // (12 B per path; 0.94 GB for 512x512x300, nothing against 288 GB of HBM) and
 // k_accumulate adds the staged samples per pixel in iteration order afterwards.
 constexpr uint32_t kGrab = 512;
+// One camera ray parked in a wavefront's LDS ring (k_queue).
+struct alignas(16) RaySlot { float px, py, pz, dx; float dy, dz; uint32_t pixel, itk; };
+static_assert(sizeof(RaySlot) == 32, "RaySlot");
+constexpr uint32_t kRing = 128;
+
 #ifndef TRC_QUEUE_WAVES
 #define TRC_QUEUE_WAVES 5          // resident waves per SIMD the kernel is compiled for
 #endif
@@ -263,46 +268,67 @@ constexpr uint32_t kGrab = 512;
 __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                     uint32_t n_iters, float* __restrict__ stage,
                                                     uint32_t* __restrict__ next_task, DeviceCounters* counters) {
+  __shared__ RaySlot s_ring[kMaxWavesPerBlock * kRing];
+  RaySlot* __restrict__ ring = s_ring + (threadIdx.x >> 6) * kRing;
   const uint32_t total = fp.npix * n_iters;
   const unsigned lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: task ids this wave has reserved
+  uint32_t ring_head = 0, ring_count = 0;    // wave-uniform: camera rays waiting in this wave's LDS ring
   bool exhausted = false;                    // wave-uniform: the global queue is empty
   bool have = false;                         // this lane carries a live path
   uint32_t pixel = 0, itk = 0, iter = 0;
   int depth = 0;
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
-  f3 col = splat3(0.0f);
+  f3 col = splat3(1.0f);
   uint32_t live = 0, tt = 0, paths = 0;
 
   while (true) {
-    unsigned long long need = __ballot(!have);
-    while (need != 0ull && !exhausted) {
-      if (pool_next == pool_end) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(next_task, kGrab);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= total) { exhausted = true; break; }
-        pool_next = base;
-        pool_end = (total - base < kGrab) ? total : base + kGrab;
-      }
-      const uint32_t avail = pool_end - pool_next;
-      const uint32_t rank = __popcll(need & lt_mask);
-      if (!have && rank < avail) {
+    const unsigned long long need = __ballot(!have);
+    if (need != 0ull) {
+      const uint32_t n_need = __popcll(need);
+      // Camera rays are generated 64 at a time by the WHOLE wavefront into the ring (ring_count < 64
+      // here, so at most 127 of its kRing = 128 slots are ever in use); finished lanes then just pick
+      // one up. Generating only for the lanes that happen to be idle ran this code at ~27 % lane use.
+      while (ring_count < n_need && !exhausted) {
+        if (pool_next == pool_end) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(next_task, kGrab);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (base >= total) { exhausted = true; break; }
+          pool_next = base;
+          pool_end = (total - base < kGrab) ? total : base + kGrab;
+        }
+        const uint32_t avail = pool_end - pool_next;
+        const uint32_t take = avail < 64u ? avail : 64u;
+        const bool gen = lane < take;
         TRC_MARK("regen");
-        const uint32_t id = pool_next + rank;
-        itk = udivmod(id, fp.div_npix, pixel);
+        uint32_t g_pixel;
+        const uint32_t g_itk = udivmod(gen ? pool_next + lane : 0u, fp.div_npix, g_pixel);
+        const Ray g = camera_sample(fp, g_pixel, iter_first + g_itk * iter_stride, gen);
+        if (gen) {
+          RaySlot& o = ring[(ring_head + ring_count + lane) & (kRing - 1u)];
+          o.px = g.pos.x; o.py = g.pos.y; o.pz = g.pos.z; o.dx = g.dir.x; o.dy = g.dir.y; o.dz = g.dir.z;
+          o.pixel = g_pixel; o.itk = g_itk;
+        }
+        TRC_MARK("regen_end");
+        pool_next += take;
+        ring_count += take;
+      }
+      const uint32_t rank = __popcll(need & lt_mask);
+      if (!have && rank < ring_count) {
+        const RaySlot& o = ring[(ring_head + rank) & (kRing - 1u)];
+        ray.pos = mk3(o.px, o.py, o.pz); ray.dir = mk3(o.dx, o.dy, o.dz);
+        pixel = o.pixel; itk = o.itk;
         iter = iter_first + itk * iter_stride;
-        ray = camera_sample(fp, pixel, iter);
         col = splat3(1.0f);
         depth = 0;
         have = true;
         ++paths;
-        TRC_MARK("regen_end");
       }
-      const uint32_t wanted = __popcll(need);
-      pool_next += (wanted < avail) ? wanted : avail;
-      need = __ballot(!have);
+      const uint32_t taken = n_need < ring_count ? n_need : ring_count;
+      ring_head = (ring_head + taken) & (kRing - 1u);
+      ring_count -= taken;
     }
     if (__ballot(have) == 0ull) break;
     const int res = bounce_step(fp, have, pixel, iter, depth, ray, col, tt);
