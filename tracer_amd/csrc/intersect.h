@@ -254,31 +254,60 @@ __device__ __forceinline__ void consider(Closest& c, const Ray& ray, float t, ui
   if (better) { c.mindist = dist; c.t = t; c.id = (int)id; c.pos = wpos; c.nor = wnor; }
 }
 
-// K planes at once, branch-free. Ray.inl:142-158: t = -o.y/d.y, hit iff |x|,|z| < 0.5 (strict);
-// the normal is always object +y -> DevXform::nor_y.
+// ---- planes and spheres: hold the candidate, transform it once -----------------------------------
+// A ray usually has a positive hit on ONE object of a group (one wall of a box, one of a few
+// spheres), yet Ray.inl:59-64 + :72-74 (world position, world normal, distance, the running
+// comparison) cost as much as the intersection itself. So each lane HOLDS its candidate (t, object
+// space point, object number) while the group is walked, and the world-space half runs once per
+// group with the held object's matrix gathered per lane. If any lane meets a second candidate
+// while holding one, the wave flushes first -- every candidate still goes through consider() in
+// object order, so the result is the one the plain loop produces.
+struct Held { bool any; float t; f3 p; uint32_t k; };
+
+template <bool SPHERE>
+__device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const DevXform* __restrict__ xf, Held& h) {
+  if (__ballot(h.any) == 0ull) return;
+  if (h.any) {
+    const DevXform& x = xf[h.k];                                // per-lane gather (a handful of distinct records)
+    const Affine m = x.m;
+    f3 wn = x.nor_y;                                            // planes: object +y (Ray.inl:156, :62)
+    if (SPHERE) wn = normalize_dev(xform_dir(m, normalize_dev(h.p, true)), true);   // Ray.inl:116, :62
+    consider(c, ray, h.t, x.id, m, h.p, wn);
+  }
+  h.any = false;
+}
+template <bool SPHERE>
+__device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform* __restrict__ xf, Held& h,
+                                     bool cand, float t, f3 p, uint32_t k) {
+  if (__ballot(cand & h.any) != 0ull) flush_held<SPHERE>(c, ray, xf, h);
+  if (cand) { h.any = true; h.t = t; h.p = p; h.k = k; }
+}
+
+// K planes at once. Ray.inl:142-158: t = -o.y/d.y, hit iff |x|,|z| < 0.5 (strict); the normal is
+// always object +y -> DevXform::nor_y. Only t > 0 competes (Ray.inl:72).
 template <int K>
-__device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf) {
-  Ray r[K]; float t[K]; f3 p[K];
+__device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf,
+                                       uint32_t first, Held& h) {
+  Ray r[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[k].mi, live);    // Ray.inl:88
+  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[first + k].mi, live);    // Ray.inl:88
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const float tp = -r[k].pos.y / r[k].dir.y;
-    p[k] = r[k].pos + tp * r[k].dir;
-    const bool in = (p[k].x < 0.5f) & (p[k].z < 0.5f) & (p[k].x > -0.5f) & (p[k].z > -0.5f);
-    t[k] = in ? tp : -1.0f;
+    const f3 p = r[k].pos + tp * r[k].dir;
+    const bool in = (p.x < 0.5f) & (p.z < 0.5f) & (p.x > -0.5f) & (p.z > -0.5f);
+    hold<false>(c, ray, xf, h, live & in & (tp > 0.0f), tp, p, first + k);
   }
-#pragma unroll
-  for (int k = 0; k < K; ++k) consider(c, ray, t[k], xf[k].id, xf[k].m, p[k], xf[k].nor_y);
 }
 
 // K spheres at once. Ray.inl:103-118: radius 0.5, geometric method, normal = normalize(pos),
-// then Ray.inl:62 normalize(M * (n, 0)).
+// then Ray.inl:62 normalize(M * (n, 0)) -- both only for a held candidate (flush_held).
 template <int K>
-__device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf) {
-  Ray r[K]; float t[K]; f3 p[K], wn[K];
+__device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf,
+                                        uint32_t first, Held& h) {
+  Ray r[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[k].mi, live);
+  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[first + k].mi, live);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const f3 l = -r[k].pos;
@@ -288,13 +317,9 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, c
     const bool hit = live & !((s < 0.0f) & (l2 > 0.25f)) & !(m2 > 0.25f);
     const float q = cr_sqrt(0.25f - m2, hit);
     const float th = (l2 > 0.25f) ? s - q : s + q;
-    t[k] = hit ? th : -1.0f;
-    p[k] = r[k].pos + r[k].dir * th;
-    const bool use = hit & (th > 0.0f);                        // only a competing hit's normal is observable
-    wn[k] = normalize_dev(xform_dir(xf[k].m, normalize_dev(p[k], use)), use);
+    const f3 p = r[k].pos + r[k].dir * th;
+    hold<true>(c, ray, xf, h, hit & (th > 0.0f), th, p, first + k);
   }
-#pragma unroll
-  for (int k = 0; k < K; ++k) consider(c, ray, t[k], xf[k].id, xf[k].m, p[k], wn[k]);
 }
 
 // Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
@@ -337,13 +362,16 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevS
   Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
   const DevXform* __restrict__ xf = sc.xf;
   uint32_t i = 0;
+  Held h; h.any = false; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u;
   TRC_MARK("planes");
-  for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, live, xf + i);
-  if (i < sc.n_plane) planes<1>(c, ray, live, xf + i);
+  for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, live, xf, i, h);
+  if (i < sc.n_plane) planes<1>(c, ray, live, xf, i, h);
+  flush_held<false>(c, ray, xf, h);
   xf += sc.n_plane;
   TRC_MARK("spheres");
-  for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, live, xf + i);
-  if (i < sc.n_sphere) spheres<1>(c, ray, live, xf + i);
+  for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, live, xf, i, h);
+  if (i < sc.n_sphere) spheres<1>(c, ray, live, xf, i, h);
+  flush_held<true>(c, ray, xf, h);
   xf += sc.n_sphere;
   TRC_MARK("cubes");
   for (i = 0; i < sc.n_cube; ++i) cube(c, ray, live, xf[i], sc.cubes[i]);
@@ -351,8 +379,8 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevS
   TRC_MARK("meshes");
   for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc.tris, tri_tests);
   TRC_MARK("closest_done");
-  Hit h; h.t = c.t; h.id = c.id; h.pos = c.pos; h.nor = c.nor;
-  return h;
+  Hit out; out.t = c.t; out.id = c.id; out.pos = c.pos; out.nor = c.nor;
+  return out;
 }
 
 } // namespace trc
