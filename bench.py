@@ -34,7 +34,8 @@ FLOP_PER_SEGMENT = 880.0
 FLOP_PER_PATH = 118.0          # ray generation (~103) + accumulate (~15)
 BYTES_PER_SEGMENT_REF = 108.0  # reference buffer layout, SURVEY.md 8(d)
 PEAK_FP32_TFLOPS = 157.3       # MI355X FP32 vector peak (packed FMA), MI355X_MICROARCH.md
-PEAK_FP32_UNFUSED_TFLOPS = 39.3  # one unfused, unpacked add/mul per lane per clock
+PEAK_FP32_UNFUSED_TFLOPS = 65.5  # measured (tools/micro/inst_cost.hip): v_mul_f32 / v_add_f32 issue every ~2.4
+                                 # cycles per wave64 per SIMD at 8 waves -> 64 * 1024 SIMDs * 2.4 GHz / 2.4
 PEAK_HBM_GBS = 8000.0
 
 
