@@ -39,6 +39,20 @@ PEAK_FP32_UNFUSED_TFLOPS = 65.5  # measured (tools/micro/inst_cost.hip): v_mul_f
 PEAK_HBM_GBS = 8000.0
 
 
+def measured_hbm_traffic():
+    """HBM bytes of one k_queue launch of this workload from the committed rocprofv3 PMC passes
+    (tools/pmc_hbm.sh -> profiles/*_hbm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", "*_hbm.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["per_kernel"]["trc::k_queue"]
+        return int((k["hbm_read_MB_gfx950_corrected_x2"] + k["hbm_write_MB"]) * 1048576), os.path.basename(files[-1])
+    except (KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline():
     """Time the CPU oracle (plain-C restatement, bit-identical to the reference host build)
     on this box's host cores over a bounded sample of the same workload."""
@@ -190,16 +204,21 @@ def main():
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS,
-                "frac_unfused": round(achieved / PEAK_FP32_UNFUSED_TFLOPS, 4),
+                "peak_unfused_measured": PEAK_FP32_UNFUSED_TFLOPS,
+                "frac_unfused_measured": round(achieved / PEAK_FP32_UNFUSED_TFLOPS, 4),
+                "peak_unfused_nominal": 39.3,      # 16 lanes/SIMD/clock
+                "frac_unfused_nominal": round(achieved / 39.3, 4),
                 "kernel_ms": round(k_ms, 4),
                 "flop_per_segment": FLOP_PER_SEGMENT,
                 "flop_per_path": FLOP_PER_PATH,
                 "traffic": None,
+                "traffic_source": None,
                 "hbm_algorithmic_GBs": round(seg_per_launch * BYTES_PER_SEGMENT_REF / (k_ms * 1e-3) / 1e9, 2),
                 "hbm_peak_GBs": PEAK_HBM_GBS,
             },
         }
+        if args.pipeline == 3:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_hbm_traffic()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
