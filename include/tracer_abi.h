@@ -73,13 +73,18 @@ typedef enum trc_rng_mode { TRC_RNG_REFERENCE = 0, TRC_RNG_DECORRELATED = 1 } tr
  *  TRC_PIPE_QUEUE       persistent wavefronts pull (pixel, iteration) path tasks from a global
  *                       work queue, so lanes never idle on short paths or cheap pixels; the
  *                       samples pass through a staging buffer in HBM and are summed per pixel
- *                       in iteration order by a second kernel (default).                    */
+ *                       in iteration order by a second kernel;
+ *  TRC_PIPE_AUTO       TRC_PIPE_QUEUE, except for a scene with a MESH of 1024 triangles or more:
+ *                       then TRC_PIPE_COMPACTED, where the brute-force loop over that mesh's faces
+ *                       (Ray.inl:172-177) runs as a pass of its own before every bounce, over a
+ *                       dense queue of the rays that passed its AABB, with the triangle list
+ *                       staged through LDS in tiles (default).                              */
 typedef enum trc_pipeline { TRC_PIPE_WAVEFRONT = 0, TRC_PIPE_COMPACTED = 1, TRC_PIPE_FUSED = 2,
-                            TRC_PIPE_QUEUE = 3 } trc_pipeline;
+                            TRC_PIPE_QUEUE = 3, TRC_PIPE_AUTO = 4 } trc_pipeline;
 
 typedef enum trc_option {
   TRC_OPT_RNG_MODE = 0,     /* trc_rng_mode, default TRC_RNG_REFERENCE */
-  TRC_OPT_PIPELINE = 1,     /* trc_pipeline, default TRC_PIPE_QUEUE */
+  TRC_OPT_PIPELINE = 1,     /* trc_pipeline, default TRC_PIPE_AUTO */
   TRC_OPT_RECORD_HITS = 2,  /* 0/1: raytrace1 also stores id/t/pos/nor per pixel (default 1) */
   TRC_OPT_STAGE_MB = 3      /* TRC_PIPE_QUEUE: staging buffer budget in MiB (default 2048); a call is
                                split into chunks of iterations that fit */

@@ -98,4 +98,10 @@ static inline ico_mesh ico_subdivide(const float* verts0, uint32_t nverts0,
   return cur;
 }
 
+/* Object-space radius the scenes give the level-`levels` icosphere: 2^max(0, levels-3). Ray.inl:196
+ * rejects every triangle with |det| < EPS = 0.001 (absolute) and |det| <= |e1 x e2|, so on the unit
+ * sphere the faces of level 5 and above would all be rejected; the vertices are scaled by this
+ * power of two (exact) and the object scaled down by it, normals stay unit vectors. */
+static inline float ico_radius(int levels) { return levels > 3 ? (float)(1u << (levels - 3)) : 1.0f; }
+
 #endif

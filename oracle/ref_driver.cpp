@@ -171,8 +171,11 @@ void* orc_scene_create(int variant, int param, const char* data_dir) {
       faces[i].m_n = faces[i].m_v;
     }
     free(im.verts); free(im.faces);
-    Object::Object* obj = Object::newObject(Mesh::fromArrays(verts, verts, faces));
-    Object::scale(*obj, 3.0f);
+    const float radius = ico_radius(param);                       // icosphere.h: keeps |det| above EPS
+    std::vector<glm::vec3> scaled(verts);
+    for (size_t i = 0; i < scaled.size(); ++i) scaled[i] = scaled[i] * radius;
+    Object::Object* obj = Object::newObject(Mesh::fromArrays(scaled, verts, faces));
+    Object::scale(*obj, 3.0f / radius);
     Object::translate(*obj, glm::vec3(0.0f, -2.0f, 0.0f));
     obj->m_material.m_color = glm::vec3(1.0f, 1.0f, 0.0f);
     s->objs.push_back(*obj);

@@ -585,12 +585,14 @@ void* orc_scene_create(int variant, int param, const char* data_dir) {
     m->numVerts = im.nverts; m->numNorms = im.nverts; m->numFaces = im.nfaces;
     m->verts = (v3*)malloc(sizeof(v3) * im.nverts); memcpy(m->verts, im.verts, sizeof(v3) * im.nverts);
     m->norms = (v3*)malloc(sizeof(v3) * im.nverts); memcpy(m->norms, im.verts, sizeof(v3) * im.nverts);
+    const float radius = ico_radius(param);                       /* icosphere.h: keeps |det| above EPS */
+    for (uint i = 0; i < im.nverts; ++i) { m->verts[i].x *= radius; m->verts[i].y *= radius; m->verts[i].z *= radius; }
     m->faces = (Face*)malloc(sizeof(Face) * im.nfaces);
     for (uint i = 0; i < im.nfaces; ++i) for (int c = 0; c < 3; ++c) { m->faces[i].v[c] = im.faces[3*i+c]; m->faces[i].n[c] = im.faces[3*i+c]; }
     free(im.verts); free(im.faces);
     mesh_bounds(m);
     o[k] = newObject(m);
-    obj_scale(&o[k], v3s(3.0f));
+    obj_scale(&o[k], v3s(3.0f / ico_radius(param)));
     obj_translate(&o[k], V3(0.0f, -2.0f, 0.0f));
     o[k].material.color = V3(1.0f, 1.0f, 0.0f); ++k;
   } else { free(s->objs); free(s); return NULL; }

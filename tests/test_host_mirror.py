@@ -56,7 +56,7 @@ def _flatten_objects(raw, n):
     return out
 
 
-@pytest.mark.parametrize("variant,param", [(0, 0), (1, 0), (2, 2)])
+@pytest.mark.parametrize("variant,param", [(0, 0), (1, 0), (2, 2), (2, 5)])
 def test_cornell_scene_equals_oracle(product_lib, oracle_c, variant, param):
     import tracer_amd as ta
     sc = ta.Scene(variant, param); s = oracle_c.scene_create(variant, param)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 
-@pytest.mark.parametrize("variant,param", [(0, 0), (1, 0), (2, 2)])
+@pytest.mark.parametrize("variant,param", [(0, 0), (1, 0), (2, 2), (2, 4)])
 def test_scene_and_mode1(oracle_c, oracle_ref, variant, param):
     sr = oracle_ref.scene_create(variant, param); sc = oracle_c.scene_create(variant, param)
     assert oracle_ref.scene_size(sr) == oracle_c.scene_size(sc)

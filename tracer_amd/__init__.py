@@ -6,4 +6,4 @@ __graft_entry__.py drive it through. There is NO CPU fallback: importing `tracer
 without the built library raises.
 """
 from .api import (Tracer, Scene, camera_default, write_ppm, write_pfm, Camera, Counters, TracerError, lib_path, load_library,  # noqa: F401
-                  RNG_REFERENCE, RNG_DECORRELATED, PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED, PIPE_QUEUE)
+                  RNG_REFERENCE, RNG_DECORRELATED, PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED, PIPE_QUEUE, PIPE_AUTO)

@@ -6,7 +6,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RNG_REFERENCE, RNG_DECORRELATED = 0, 1
-PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED, PIPE_QUEUE = 0, 1, 2, 3
+PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED, PIPE_QUEUE, PIPE_AUTO = 0, 1, 2, 3, 4
 OPT_RNG_MODE, OPT_PIPELINE, OPT_RECORD_HITS, OPT_STAGE_MB = 0, 1, 2, 3
 
 # every symbol include/tracer_abi.h declares

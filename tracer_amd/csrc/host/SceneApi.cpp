@@ -178,8 +178,18 @@ Mesh* icosphere(const Mesh& base, int levels) {
   std::vector<Face> faces(tri.size() / 3);
   for (size_t i = 0; i < faces.size(); ++i)
     for (int k = 0; k < 3; ++k) { faces[i].v[k] = tri[3 * i + k]; faces[i].n[k] = tri[3 * i + k]; }
-  return make_mesh(verts, verts, faces);
+  // Ray.inl:196 rejects a triangle when |det| < EPS = 0.001 (absolute), and |det| <= |e1 x e2|: on the
+  // unit sphere every face of level 5 and above is smaller than that and the mesh would be invisible.
+  // From level 4 on the vertices are therefore scaled by 2^(level-3) (exact in binary) and the caller
+  // scales the object down by the same factor; the normals stay the unit vectors.
+  const float radius = icosphereRadius(levels);
+  if (radius == 1.0f) return make_mesh(verts, verts, faces);
+  std::vector<f3> scaled(verts);
+  for (f3& v : scaled) v = trc::mk3(v.x * radius, v.y * radius, v.z * radius);
+  return make_mesh(scaled, verts, faces);
 }
+
+float icosphereRadius(int levels) { return levels > 3 ? (float)(1u << (levels - 3)) : 1.0f; }
 
 void freeMesh(Mesh* m) {
   if (!m) return;

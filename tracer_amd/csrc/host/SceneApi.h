@@ -34,6 +34,7 @@ namespace Mesh {
   // Icosphere: `levels` 4-to-1 subdivisions of a base mesh's faces, vertices pushed to the unit
   // sphere, normals = positions (BASELINE.json configs[4]; no counterpart in the reference).
   Mesh* icosphere(const Mesh& base, int levels);
+  float icosphereRadius(int levels);   // object-space radius of icosphere(base, levels): 2^max(0, levels-3)
   void freeMesh(Mesh* m);
 }
 

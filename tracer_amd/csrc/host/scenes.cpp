@@ -92,7 +92,7 @@ int trc_scene_cornell(int variant, int param, const char* data_dir, trc_scene** 
     if (variant == 1) { solid.material.type = Material::TRANS; solid.material.n = 1.6f; }
   } else {
     Object::Object& ball = s->add(s->own(Mesh::icosphere(*ico, param)));
-    Object::scale(ball, 3.0f);
+    Object::scale(ball, 3.0f / Mesh::icosphereRadius(param));      // world radius 3 at every level
     Object::translate(ball, mk3(0.0f, -2.0f, 0.0f));
     ball.material.color = mk3(1.0f, 1.0f, 0.0f);
   }

@@ -340,14 +340,31 @@ __device__ __forceinline__ void cube(Closest& c, const Ray& ray, bool live, cons
   consider(c, ray, hit ? th : -1.0f, xf.id, xf.m, p, wn);
 }
 
-// Ray.inl:160-186 (MESH): AABB slab test, then mesh_closest().
+// Ray.inl:160-186 (MESH): AABB slab test, then the closest triangle -- from mesh_closest(), or, for a
+// big mesh whose brute-force pass ran before this kernel (kernels.hip: k_mesh_brute), from that pass's
+// (t, face) key of this ray slot: the winning face is then evaluated once more for its normal
+// (same arithmetic, same t).
 __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, const DevXform& xf,
-                                     const DevMeshExtra& ex, const DevTri* __restrict__ tris, uint32_t& tri_tests) {
+                                     const DevMeshExtra& ex, const DevScene& sc, uint32_t slot, uint32_t& tri_tests) {
   const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
   const bool pass = live && slab(r, ex.bmin, ex.bmax, tNear, tFar);
   f3 bn;
-  const float tb = mesh_closest(r, pass, tris, ex, bn, tri_tests);
+  float tb;
+  if (sc.mesh_keys != nullptr && ex.big_slot != kNotBig) {
+    tb = FLT_MAX; bn = splat3(0.0f);
+    if (pass) {
+      tri_tests += ex.tri_count;
+      const unsigned long long key = sc.mesh_keys[(size_t)ex.big_slot * sc.key_stride + slot];
+      if ((uint32_t)(key >> 32) != 0x7f7fffffu) {
+        f3 n;
+        const float t = hit_triangle(r, sc.tris[ex.tri_first + (uint32_t)key], n);
+        if (t > 0.0f) { tb = t; bn = n; }
+      }
+    }
+  } else {
+    tb = mesh_closest(r, pass, sc.tris, ex, bn, tri_tests);
+  }
   // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero normal
   // forward; the world-space distance test then rejects it because |o + d*FLT_MAX|^2 overflows
   // to inf for any normalised d -> explicit miss here.
@@ -358,7 +375,8 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, cons
 }
 
 // Wave-convergent (see the header comment).
-__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevScene& sc, uint32_t& tri_tests) {
+// `slot`: this ray's row in the key table of the big-mesh passes (unused while sc.mesh_keys is null).
+__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevScene& sc, uint32_t& tri_tests, uint32_t slot = 0u) {
   Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
   const DevXform* __restrict__ xf = sc.xf;
   uint32_t i = 0;
@@ -377,7 +395,7 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevS
   for (i = 0; i < sc.n_cube; ++i) cube(c, ray, live, xf[i], sc.cubes[i]);
   xf += sc.n_cube;
   TRC_MARK("meshes");
-  for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc.tris, tri_tests);
+  for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc, slot, tri_tests);
   TRC_MARK("closest_done");
   Hit out; out.t = c.t; out.id = c.id; out.pos = c.pos; out.nor = c.nor;
   return out;

@@ -43,9 +43,29 @@ struct DeviceCounters {
   unsigned long long tri_tests;
 };
 
-// mode 1 (raytrace.cu:29-62). hit_* may be null.
+// ---- big meshes (scene.h: kBigMeshTris): brute-force pass in front of a closest-hit kernel ------
+struct BigMesh { uint32_t mesh_index, hot_first, tri_first, tri_count; };   // host-side list, in big_slot order
+// Dense queue of the rays that passed one big mesh's AABB, in that mesh's object space.
+struct MeshRayQueue {
+  uint32_t* count;                 // rays queued (device counter)
+  uint32_t* slot;                  // ray slot of queue entry j (row of the key table)
+  float* ox; float* oy; float* oz; // object-space ray of entry j, planar
+  float* dx; float* dy; float* dz;
+};
+// What the launchers need to run those passes: the scene's big meshes, the queue (reused mesh
+// after mesh, bounce after bounce: everything is stream-ordered), the key table
+// keys[big_slot * fp.sc.key_stride + slot] (== fp.sc.mesh_keys) and the size of the persistent grid.
+struct BigMeshPass {
+  const BigMesh* big; uint32_t n_big;
+  MeshRayQueue q;
+  unsigned long long* keys;
+  unsigned grid_blocks;
+};
+
+// mode 1 (raytrace.cu:29-62). hit_* may be null; bmp is null when the scene has no big mesh.
 void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, float* hit_t,
-                      float* hit_pos, float* hit_nor, hipStream_t stream);
+                      float* hit_pos, float* hit_nor, DeviceCounters* counters, const BigMeshPass* bmp,
+                      hipStream_t stream);
 
 // mode 2, wavefront pipelines: one iteration = raygen + kPathDepth bounce launches.
 // compact = false: state stays at slot == pixel, dead paths flagged (pixel plane = -1).
@@ -53,7 +73,7 @@ void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, flo
 //                  queue_count[d] is the number of live paths entering bounce d.
 void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compact,
                                 PathState cur, PathState next, uint32_t* queue_count /*[kPathDepth+1]*/,
-                                float* film, DeviceCounters* counters, hipStream_t stream);
+                                float* film, DeviceCounters* counters, const BigMeshPass* bmp, hipStream_t stream);
 
 // mode 2, fused persistent pipeline: all iterations of the call in one launch.
 void launch_fused(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,

@@ -18,6 +18,8 @@ namespace trc {
 
 constexpr int kBlock = 256;
 
+static inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
 // ---- wave64 helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
@@ -67,8 +69,8 @@ __device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx
 enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE = 3 };
 
 __device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uint32_t pixel, uint32_t iter, int depth,
-                                           Ray& ray, f3& col, uint32_t& tri_tests) {
-  Hit hit = closest_hit(ray, live, fp.sc, tri_tests);
+                                           Ray& ray, f3& col, uint32_t& tri_tests, uint32_t slot = 0u) {
+  Hit hit = closest_hit(ray, live, fp.sc, tri_tests, slot);
   if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
   const DevMaterial& o = fp.sc.mats[hit.id];
@@ -94,12 +96,14 @@ __device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uin
 // ---- mode 1: raytraceKernel, raytrace.cu:29-62 ---------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* __restrict__ ldr,
                                                      int32_t* __restrict__ hit_id, float* __restrict__ hit_t,
-                                                     float* __restrict__ hit_pos, float* __restrict__ hit_nor) {
+                                                     float* __restrict__ hit_pos, float* __restrict__ hit_nor,
+                                                     DeviceCounters* counters) {
   uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = idx < fp.npix;          // no early return: closest_hit is wave-convergent
   Ray ray = primary_ray(fp, idx);
   uint32_t tt = 0;
-  Hit hit = closest_hit(ray, valid, fp.sc, tt);
+  Hit hit = closest_hit(ray, valid, fp.sc, tt, idx);
+  if (counters) count_add(&counters->tri_tests, (unsigned long long)tt);
   if (!valid) return;
   const f3 lightDir = mk3((float)0.267261, (float)0.801784, (float)0.534522);
   f3 col;
@@ -117,6 +121,193 @@ __global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* 
   if (hit_t) hit_t[idx] = hit.t;
   if (hit_pos) { hit_pos[3 * idx] = hit.pos.x; hit_pos[3 * idx + 1] = hit.pos.y; hit_pos[3 * idx + 2] = hit.pos.z; }
   if (hit_nor) { hit_nor[3 * idx] = hit.nor.x; hit_nor[3 * idx + 1] = hit.nor.y; hit_nor[3 * idx + 2] = hit.nor.z; }
+}
+
+// ---- big meshes: brute-force closest triangle as a pass of its own ---------------------------------
+// Ray.inl:172-177 tests EVERY face of a MESH for every ray that passed its AABB. For a mesh of a
+// million triangles that loop is the whole cost of a frame, so the launch-per-bounce pipelines
+// (mode 1, wavefront, compacted) take it out of closest_hit():
+//   k_mesh_rays   every live ray is brought to the mesh's object space and slab-tested exactly as
+//                 mesh() does; the passing rays are appended to a dense queue by wavefront ballot;
+//   k_mesh_brute  a workgroup owns 512 queued rays (two per lane, in registers) and a contiguous
+//                 segment of the triangle list, which it stages through LDS in tiles of 256 HotTri
+//                 records (36 useful bytes each; coalesced copy, then every lane reads the SAME
+//                 record: a broadcast, no bank conflicts). (ray block, segment) work items are
+//                 handed to a fixed grid round-robin, segment-major, so the workgroups running
+//                 at any moment stream the same part of the list out of L2.
+//                 The closest hit of a ray is the minimum of (bits of t) << 32 | face over all
+//                 segments, joined with one atomicMin per ray and segment: positive floats order
+//                 as their bits, and among equal t the lowest face wins, which is the reference's
+//                 strict `<` in face order (Ray.inl:174);
+//   closest_hit() then looks the key up and evaluates the winning face once more for its normal.
+// Per (ray, triangle) the exact Moeller-Trumbore arithmetic runs up to det and u = dot(tvec, pvec);
+// 1/det and bary.x = u * (1/det) are NOT formed when the outcome of Ray.inl:196 / :203 is already
+// certain from u and det themselves. With c = 0.500005:
+//   |det| < EPS                    -> rejected at :196
+//   |u - c*det| > |c*det|          -> u/det > 2c = 1.00001 or u/det < -1.5e-8, so fl(u * fl(1/det)) is
+//                                     > 1 or < 0 at :203 (bary.x in [0, 1] <=> |u/det - 1/2| <= 1/2)
+// c*det and the difference are each rounded once (2^-24 relative) and rounding is monotonic, so
+// the strict comparison can only hold with the true values at least that far out -- margins of
+// 1e-5 and 1.5e-8 against 1.2e-7 of error in u * fl(1/det) and no underflow to -0. A NaN makes the
+// comparisons false, i.e. "not certain". Only when some lane of the wavefront is not certain --
+// about one (ray, triangle) pair in 10^5 -- does the wavefront run the full test.
+constexpr unsigned long long kKeyNone = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // t = FLT_MAX
+
+// SOURCE 0: primary rays of mode 1 (slot = pixel). SOURCE 1: the live paths of a bounce pass
+// (slot = position in the path-state arrays; n_in from the queue counter when compacting).
+template <int SOURCE>
+__global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t mesh_index, PathState cur,
+                                                     const uint32_t* __restrict__ count_in, MeshRayQueue q,
+                                                     unsigned long long* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t n_in = (SOURCE == 1 && count_in) ? *count_in : fp.npix;
+  if (blockIdx.x * kBlock >= n_in) return;
+  bool live = i < n_in;
+  Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
+  if (SOURCE == 0) {
+    ray = primary_ray(fp, i);
+  } else {
+    live = live && cur.pixel[i] >= 0;
+    if (live) { ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]); ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]); }
+  }
+  const DevXform& xf = fp.sc.xf[fp.sc.n_plane + fp.sc.n_sphere + fp.sc.n_cube + mesh_index];
+  const DevMeshExtra& ex = fp.sc.meshes[mesh_index];
+  const Ray r = to_object_space(ray, xf.mi, live);                       // exactly as mesh() in intersect.h
+  float tNear, tFar;
+  const bool pass = live && slab(r, ex.bmin, ex.bmax, tNear, tFar);
+  // a ray with a NaN coordinate passes the slab test (Ray.inl:167 is written with `>` and `<`) and then
+  // fails every triangle, because each t it produces is NaN; it gets the "no hit" key without being queued.
+  const bool finite = (r.pos.x == r.pos.x) & (r.pos.y == r.pos.y) & (r.pos.z == r.pos.z) &
+                      (r.dir.x == r.dir.x) & (r.dir.y == r.dir.y) & (r.dir.z == r.dir.z);
+  if (pass) keys[(size_t)ex.big_slot * fp.sc.key_stride + i] = kKeyNone;
+  const bool enq = pass & finite;
+  const unsigned long long mask = __ballot(enq);
+  const unsigned n = __popcll(mask);
+  if (n == 0) return;
+  const unsigned lane = lane_id();
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(q.count, n);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  if (enq) {
+    const uint32_t j = base + __popcll(mask & ((1ull << lane) - 1ull));
+    q.slot[j] = i;
+    q.ox[j] = r.pos.x; q.oy[j] = r.pos.y; q.oz[j] = r.pos.z;
+    q.dx[j] = r.dir.x; q.dy[j] = r.dir.y; q.dz[j] = r.dir.z;
+  }
+}
+
+constexpr int kRaysPerLane = 2;    // rays a lane of k_mesh_brute carries: every LDS broadcast of a triangle record
+                                   // (48 B x 64 lanes through the LDS return path) then feeds two tests
+constexpr uint32_t kBruteRays = kBlock * kRaysPerLane;   // rays per work item
+
+__global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const HotTri* __restrict__ hot,
+                                                      const DevTri* __restrict__ cold, uint32_t tri_count, uint32_t n_tiles,
+                                                      uint32_t tiles_per_seg, uint32_t n_segs,
+                                                      unsigned long long* __restrict__ keys) {
+  __shared__ float4 s_tile[kMeshTile * 3];
+  const uint32_t nq = *q.count;
+  const uint32_t n_rb = (nq + kBruteRays - 1) / kBruteRays;
+  const uint32_t n_items = n_rb * n_segs;
+  const unsigned lane = lane_id();
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t seg = item / n_rb;
+    const uint32_t rb = item - seg * n_rb;
+    // Lanes past the end of the queue carry a zero ray: det == 0, "certain" for every triangle.
+    f3 o[kRaysPerLane], d[kRaysPerLane];
+    uint32_t slot[kRaysPerLane];
+    bool valid[kRaysPerLane];
+    unsigned long long best[kRaysPerLane];
+#pragma unroll
+    for (int r = 0; r < kRaysPerLane; ++r) {
+      const uint32_t j = rb * kBruteRays + r * kBlock + threadIdx.x;
+      valid[r] = j < nq;
+      o[r] = splat3(0.0f); d[r] = splat3(0.0f); slot[r] = 0; best[r] = kKeyNone;
+      if (valid[r]) { slot[r] = q.slot[j]; o[r] = mk3(q.ox[j], q.oy[j], q.oz[j]); d[r] = mk3(q.dx[j], q.dy[j], q.dz[j]); }
+    }
+    const uint32_t tile0 = seg * tiles_per_seg;
+    const uint32_t tile1 = (tile0 + tiles_per_seg < n_tiles) ? tile0 + tiles_per_seg : n_tiles;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(hot);
+    // this lane's record of the first tile (records are padded to whole tiles at upload)
+    float4 r0 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 0];
+    float4 r1 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 1];
+    float4 r2 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 2];
+    for (uint32_t tile = tile0; tile < tile1; ++tile) {
+      __syncthreads();                                     // everyone is done with the previous tile
+      s_tile[threadIdx.x * 3 + 0] = r0; s_tile[threadIdx.x * 3 + 1] = r1; s_tile[threadIdx.x * 3 + 2] = r2;
+      __syncthreads();
+      if (tile + 1 < tile1) {                              // next tile's record is in flight during the tests
+        r0 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 0];
+        r1 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 1];
+        r2 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 2];
+      }
+      if (__ballot(valid[0]) == 0ull) continue;            // a wavefront past the end of the queue only helps copying
+      // one triangle record against this lane's rays
+      auto test = [&](const float4& a, const float4& b, const float4& c, uint32_t k) {
+        const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+        unsigned long long open_mask[kRaysPerLane], any_open = 0ull;
+#pragma unroll
+        for (int r = 0; r < kRaysPerLane; ++r) {
+          const f3 pvec = cross(d[r], e2);                 // Ray.inl:193-194
+          const float det = dot(e1, pvec);
+          const f3 tvec = o[r] - v0;                       // Ray.inl:199
+          const float u = dot(tvec, pvec);                 // bary.x = u * (1 / det), Ray.inl:201
+          const float cd = det * 0.500005f;
+          const float t1 = u - cd;
+          // lanes that are NOT certain: !(|det| < EPS) & !(|u - c*det| > |c*det|), as one wave mask
+          asm("v_cmp_nlt_f32 vcc, |%1|, %3\n\t"
+              "v_cmp_ngt_f32 %0, |%2|, |%4|\n\t"
+              "s_and_b64 %0, %0, vcc"
+              : "=&s"(open_mask[r]) : "v"(det), "v"(t1), "s"(kEps), "v"(cd) : "vcc");
+          any_open |= open_mask[r];
+        }
+        if (any_open == 0ull) return;
+        // Second barycentric coordinate, same idea: v = dot(dir, qvec) is bary.y * det (Ray.inl:206-207) and
+        // Ray.inl:208 rejects when bary.y < 0 or bary.x + bary.y > 1, which is certain from
+        // |v - c*det| > |c*det| (bary.y outside [0, 1.00001]) or |(u + v) - c*det| > |c*det| (the sum is).
+#pragma unroll
+        for (int r = 0; r < kRaysPerLane; ++r) {
+          if (open_mask[r] == 0ull) continue;
+          const f3 pvec = cross(d[r], e2);
+          const float det = dot(e1, pvec);
+          const f3 tvec = o[r] - v0;
+          const float u = dot(tvec, pvec);
+          const float v = dot(d[r], cross(tvec, e1));
+          const float cd = det * 0.500005f;
+          const bool certain = (__builtin_fabsf(v - cd) > __builtin_fabsf(cd)) | (__builtin_fabsf((u + v) - cd) > __builtin_fabsf(cd));
+          open_mask[r] &= __builtin_amdgcn_ballot_w64(!certain);
+        }
+        any_open = 0ull;
+#pragma unroll
+        for (int r = 0; r < kRaysPerLane; ++r) any_open |= open_mask[r];
+        const uint32_t ti = tile * kMeshTile + k;          // face index within the mesh
+        if (any_open == 0ull || ti >= tri_count) return;
+        // the full test of Ray.inl:189-226 for the lanes that are still not certain
+        const DevTri tri = cold[ti];
+#pragma unroll
+        for (int r = 0; r < kRaysPerLane; ++r) {
+          if (open_mask[r] == 0ull) continue;
+          const bool open_lane = (open_mask[r] >> lane) & 1ull;
+          float t; f3 n;
+          const bool hit = hit_triangle_all(Ray{o[r], d[r]}, tri, valid[r] & open_lane, t, n);
+          if (hit & (t > 0.0f) & (t < FLT_MAX)) {          // Ray.inl:174
+            const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | ti;
+            best[r] = key < best[r] ? key : best[r];
+          }
+        }
+      };
+      // two register sets take turns, so the next record's LDS read is in flight during a test
+      float4 a0 = s_tile[0], b0 = s_tile[1], c0 = s_tile[2], a1, b1, c1;
+      for (uint32_t k = 0; k < kMeshTile; k += 2) {
+        a1 = s_tile[k * 3 + 3]; b1 = s_tile[k * 3 + 4]; c1 = s_tile[k * 3 + 5];
+        test(a0, b0, c0, k);
+        if (k + 2 < kMeshTile) { a0 = s_tile[k * 3 + 6]; b0 = s_tile[k * 3 + 7]; c0 = s_tile[k * 3 + 8]; }
+        test(a1, b1, c1, k + 1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRaysPerLane; ++r)
+      if (best[r] != kKeyNone) atomicMin(&keys[slot[r]], best[r]);
+  }
 }
 
 // ---- wavefront pipelines -------------------------------------------------------------------------
@@ -160,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
     ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
     col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
   }
-  const int res = bounce_step(fp, active, active ? (uint32_t)pixel : 0u, iter, depth, ray, col, tt);
+  const int res = bounce_step(fp, active, active ? (uint32_t)pixel : 0u, iter, depth, ray, col, tt, i);
   const bool cont = (res == STEP_CONTINUE);
   if (res == STEP_LIGHT) {                                            // the only non-black ending
     film[3 * pixel] += col.x; film[3 * pixel + 1] += col.y; film[3 * pixel + 2] += col.z;
@@ -371,20 +562,42 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float* __restrict__ fi
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
-static inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+// One brute-force pass per big mesh over the rays of the kernel that follows (SOURCE as k_mesh_rays).
+template <int SOURCE>
+static void launch_big_mesh_passes(const FrameParams& fp, PathState cur, const uint32_t* count_in,
+                                   const BigMeshPass& bmp, hipStream_t stream) {
+  for (uint32_t b = 0; b < bmp.n_big; ++b) {
+    const BigMesh& m = bmp.big[b];
+    const uint32_t n_tiles = (m.tri_count + kMeshTile - 1) / kMeshTile;
+    // segments of >= 16 tiles (the 256 rays of a work item are loaded once per segment), at most 64 of them
+    uint32_t tiles_per_seg = (n_tiles + 63u) / 64u;
+    if (tiles_per_seg < 16u) tiles_per_seg = 16u;
+    const uint32_t n_segs = (n_tiles + tiles_per_seg - 1) / tiles_per_seg;
+    (void)hipMemsetAsync(bmp.q.count, 0, sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(grid_for(fp.npix)), dim3(kBlock), 0, stream,
+                       fp, m.mesh_index, cur, count_in, bmp.q, bmp.keys);
+    hipLaunchKernelGGL(k_mesh_brute, dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
+                       bmp.q, fp.sc.hot + m.hot_first, fp.sc.tris + m.tri_first, m.tri_count, n_tiles,
+                       tiles_per_seg, n_segs, bmp.keys + (size_t)b * fp.sc.key_stride);
+  }
+}
 
 void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, float* hit_t,
-                      float* hit_pos, float* hit_nor, hipStream_t stream) {
+                      float* hit_pos, float* hit_nor, DeviceCounters* counters, const BigMeshPass* bmp,
+                      hipStream_t stream) {
+  if (bmp) launch_big_mesh_passes<0>(fp, PathState{}, nullptr, *bmp, stream);
   hipLaunchKernelGGL(k_raytrace1, dim3(grid_for(fp.npix)), dim3(kBlock), 0, stream,
-                     fp, ldr, hit_id, hit_t, hit_pos, hit_nor);
+                     fp, ldr, hit_id, hit_t, hit_pos, hit_nor, counters);
 }
 
 void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compact,
                                 PathState cur, PathState next, uint32_t* queue_count,
-                                float* film, DeviceCounters* counters, hipStream_t stream) {
+                                float* film, DeviceCounters* counters, const BigMeshPass* bmp, hipStream_t stream) {
   const dim3 grid(grid_for(fp.npix)), block(kBlock);
   hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter, cur, queue_count, film, counters);
   for (int d = 0; d < kPathDepth; ++d) {
+    if (bmp) launch_big_mesh_passes<1>(fp, cur, compact ? queue_count + d : nullptr, *bmp, stream);
     if (compact) {
       hipLaunchKernelGGL(k_bounce<true>, grid, block, 0, stream, fp, iter, d, cur, next,
                          queue_count + d, queue_count + d + 1, film, counters);

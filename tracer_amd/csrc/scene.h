@@ -77,12 +77,20 @@ struct alignas(16) DevMeshExtra {
   f3 bmin; uint32_t tri_first; f3 bmax; uint32_t tri_count;
   // cooperative test (intersect.h): G = min(tri_count, 64) triangles side by side, 64 / G rays per pass;
   // lane / G == (lane * group_magic) >> 16 for lane < 64
-  uint32_t group_magic, rays_per_pass, pad0, pad1;
+  uint32_t group_magic, rays_per_pass;
+  // big meshes (tri_count >= kBigMeshTris): number among the scene's big meshes (row of the per-ray
+  // key table of the brute-force pass, kernels.hip: k_mesh_brute) and first record in DevScene::hot;
+  // kNotBig for a mesh that is tested inside closest_hit().
+  uint32_t big_slot, hot_first;
 };
+constexpr uint32_t kNotBig = 0xFFFFFFFFu;
+constexpr uint32_t kBigMeshTris = 1024;     // from here on a mesh gets its own brute-force pass
+constexpr uint32_t kMeshTile = 256;         // triangles per LDS tile of that pass
 struct alignas(16) DevMaterial  { f3 color; float emit; float brdf; float ior; int32_t mat_type; int32_t pad; };
 static_assert(sizeof(DevCubeExtra) == 80 && sizeof(DevMeshExtra) == 48 && sizeof(DevMaterial) == 32, "extras");
 
 struct DevTri;
+struct HotTri;
 // Pointers into ONE device allocation holding the packed scene.
 struct DevScene {
   const DevXform*     xf;          // n_plane + n_sphere + n_cube + n_mesh records, in that order
@@ -90,7 +98,13 @@ struct DevScene {
   const DevMeshExtra* meshes;      // n_mesh
   const DevMaterial*  mats;        // nobj, indexed by ORIGINAL object index
   const DevTri*       tris;        // triangle stream
+  const HotTri*       hot;         // big meshes only: the 36 bytes per triangle every test reads
   uint32_t n_plane, n_sphere, n_cube, n_mesh;
+  // Set per launch by the host: closest (t, face) per ray slot per big mesh as found by the
+  // brute-force pass that ran before this kernel, keys[big_slot * key_stride + slot]; null in the
+  // persistent pipelines, which test big meshes inside closest_hit() like small ones.
+  const unsigned long long* mesh_keys;
+  uint32_t key_stride, n_big;
 };
 
 // Triangle stream: faces pre-gathered at upload (replaces the Face -> verts/norms double
@@ -104,6 +118,13 @@ struct alignas(16) DevTri {
   float pad[2];
 };
 static_assert(sizeof(DevTri) == 80, "DevTri");
+
+// What the brute-force pass streams: v0, e1, e2 of DevTri and nothing else (the normals are read
+// from DevTri only for the handful of triangles that pass both barycentric tests). 48-byte records =
+// three 16-byte LDS reads; a mesh's records are padded to a whole tile with all-zero triangles,
+// which every ray rejects at |det| < EPS (Ray.inl:196).
+struct alignas(16) HotTri { f3 v0; f3 e1; f3 e2; float pad[3]; };
+static_assert(sizeof(HotTri) == 48, "HotTri");
 
 struct Ray { f3 pos, dir; };
 struct Hit { float t; int id; f3 pos, nor; };

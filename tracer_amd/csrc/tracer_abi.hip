@@ -46,7 +46,7 @@ struct trc_ctx {
   bool timed = false;
 
   int rng_mode = TRC_RNG_REFERENCE;
-  int pipeline = TRC_PIPE_QUEUE;
+  int pipeline = TRC_PIPE_AUTO;
   int stage_mb = 2048;
   int record_hits = 1;
 
@@ -73,6 +73,13 @@ struct trc_ctx {
   float* stage = nullptr; size_t stage_floats = 0;
   uint32_t* next_task = nullptr;
   unsigned resident_blocks = 0;
+
+  // big meshes: brute-force pass of the launch-per-bounce pipelines (kernels.hip: k_mesh_brute)
+  std::vector<BigMesh> big;
+  unsigned long long* mesh_keys = nullptr; size_t mesh_keys_cap = 0;
+  float* mesh_queue_mem = nullptr;
+  MeshRayQueue mesh_queue = {};
+  unsigned brute_blocks = 0;
 
   DeviceCounters* counters = nullptr;
 };
@@ -101,6 +108,40 @@ int ensure_hit_buffers(trc_ctx* c) {
   HIP_TRY(hipMalloc((void**)&c->hit_pos, sizeof(float) * 3ull * c->npix));
   HIP_TRY(hipMalloc((void**)&c->hit_nor, sizeof(float) * 3ull * c->npix));
   return TRC_OK;
+}
+
+// Buffers of the big-mesh brute-force passes: key table (one row of npix keys per big mesh) and
+// the ray queue (npix entries: slot + 6 floats, and the counter).
+int ensure_big_mesh_buffers(trc_ctx* c) {
+  if (c->big.empty()) return TRC_OK;
+  const size_t need = c->big.size() * (size_t)c->npix;
+  if (need > c->mesh_keys_cap) {
+    free_dev(c->mesh_keys); c->mesh_keys_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->mesh_keys, sizeof(unsigned long long) * need));
+    c->mesh_keys_cap = need;
+  }
+  if (!c->mesh_queue_mem) {
+    HIP_TRY(hipMalloc((void**)&c->mesh_queue_mem, sizeof(float) * (7ull * c->npix + 64)));
+    float* p = c->mesh_queue_mem;
+    MeshRayQueue& q = c->mesh_queue;
+    q.slot = (uint32_t*)p;
+    q.ox = p + c->npix; q.oy = p + 2ull * c->npix; q.oz = p + 3ull * c->npix;
+    q.dx = p + 4ull * c->npix; q.dy = p + 5ull * c->npix; q.dz = p + 6ull * c->npix;
+    q.count = (uint32_t*)(p + 7ull * c->npix);
+  }
+  if (!c->brute_blocks) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->brute_blocks = (unsigned)prop.multiProcessorCount * 8u;      // 8 workgroups of 4 wavefronts per CU
+  }
+  return TRC_OK;
+}
+
+BigMeshPass big_mesh_pass(const trc_ctx* c) {
+  BigMeshPass b;
+  b.big = c->big.data(); b.n_big = (uint32_t)c->big.size();
+  b.q = c->mesh_queue; b.keys = c->mesh_keys; b.grid_blocks = c->brute_blocks;
+  return b;
 }
 
 f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -182,8 +223,10 @@ int flatten_scene(const RefObject* objs, uint32_t count, std::vector<DevObject>&
 // Group the flattened objects by primitive type and lay everything out in one buffer
 // (scene.h: DevScene). `base` is the device address the buffer will live at.
 size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>& tris,
-                  std::vector<unsigned char>& blob) {
+                  std::vector<unsigned char>& blob, std::vector<BigMesh>& big) {
   std::vector<DevXform> xf; std::vector<DevCubeExtra> cubes; std::vector<DevMeshExtra> meshes;
+  std::vector<HotTri> hot;
+  big.clear();
   std::vector<DevMaterial> mats(objs.size());
   const int order[4] = { REF_PLANE, REF_SPHERE, REF_CUBE, REF_MESH };
   for (int g = 0; g < 4; ++g)
@@ -200,7 +243,24 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
       } else if (o.mesh_type == REF_MESH) {
         DevMeshExtra e; e.bmin = o.bmin; e.tri_first = o.tri_first; e.bmax = o.bmax; e.tri_count = o.tri_count;
         const uint32_t G = o.tri_count < 64u ? (o.tri_count ? o.tri_count : 1u) : 64u;
-        e.group_magic = 65535u / G + 1u; e.rays_per_pass = 64u / G; e.pad0 = e.pad1 = 0;
+        e.group_magic = 65535u / G + 1u; e.rays_per_pass = 64u / G;
+        e.big_slot = kNotBig; e.hot_first = 0;
+        if (o.tri_count >= kBigMeshTris) {
+          // the 36 bytes per triangle that every test of the brute-force pass reads, padded to whole
+          // tiles with zero triangles (det == 0 -> rejected at Ray.inl:196 by every ray)
+          e.big_slot = (uint32_t)big.size(); e.hot_first = (uint32_t)hot.size();
+          BigMesh b; b.mesh_index = (uint32_t)meshes.size(); b.hot_first = e.hot_first;
+          b.tri_first = o.tri_first; b.tri_count = o.tri_count;
+          big.push_back(b);
+          for (uint32_t t = 0; t < o.tri_count; ++t) {
+            const DevTri& src = tris[o.tri_first + t];
+            HotTri h; memset(&h, 0, sizeof h);
+            h.v0 = src.v0; h.e1 = src.e1; h.e2 = src.e2;
+            hot.push_back(h);
+          }
+          HotTri zero; memset(&zero, 0, sizeof zero);
+          while (hot.size() % kMeshTile) hot.push_back(zero);
+        }
         meshes.push_back(e);
       }
     }
@@ -220,6 +280,7 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
   append(meshes.data(), meshes.size() * sizeof(DevMeshExtra));
   append(mats.data(), mats.size() * sizeof(DevMaterial));
   append(tris.data(), tris.size() * sizeof(DevTri));
+  append(hot.data(), hot.size() * sizeof(HotTri));
   blob.resize(blob.size() + 256);                              // slack: empty sections still get valid addresses
   return blob.size();
 }
@@ -236,16 +297,18 @@ DevScene scene_pointers(const std::vector<DevObject>& objs, const std::vector<De
   sc.cubes = (const DevCubeExtra*)p;  p += up(sc.n_cube * sizeof(DevCubeExtra));
   sc.meshes = (const DevMeshExtra*)p; p += up(sc.n_mesh * sizeof(DevMeshExtra));
   sc.mats = (const DevMaterial*)p;    p += up(objs.size() * sizeof(DevMaterial));
-  sc.tris = (const DevTri*)p;
-  (void)tris;
+  sc.tris = (const DevTri*)p;         p += up(tris.size() * sizeof(DevTri));
+  sc.hot = (const HotTri*)p;
   return sc;
 }
 
 // (Re)upload the packed scene; grows the device allocation when needed.
 int upload_packed(void*& dev, size_t& cap, DevScene& sc, const std::vector<DevObject>& objs,
-                  const std::vector<DevTri>& tris, bool objects_only) {
+                  const std::vector<DevTri>& tris, bool objects_only, std::vector<BigMesh>* big_out = nullptr) {
   std::vector<unsigned char> blob;
-  const size_t bytes = pack_scene(objs, tris, blob);
+  std::vector<BigMesh> big;
+  const size_t bytes = pack_scene(objs, tris, blob, big);
+  if (big_out) big_out->swap(big);
   if (bytes > cap) {
     if (dev) { (void)hipFree(dev); dev = nullptr; cap = 0; }
     HIP_TRY(hipMalloc(&dev, bytes));
@@ -309,6 +372,7 @@ int trc_destroy(trc_ctx* c) {
   free_dev(c->hit_id); free_dev(c->hit_t); free_dev(c->hit_pos); free_dev(c->hit_nor);
   free_dev(c->state_mem[0]); free_dev(c->state_mem[1]); free_dev(c->queue_count);
   free_dev(c->counters); free_dev(c->stage); free_dev(c->next_task);
+  free_dev(c->mesh_keys); free_dev(c->mesh_queue_mem);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -324,7 +388,7 @@ int trc_set_option(trc_ctx* c, int option, int value) {
       if (value != TRC_RNG_REFERENCE && value != TRC_RNG_DECORRELATED) return fail(TRC_ERR_INVALID, "bad rng mode");
       c->rng_mode = value; return TRC_OK;
     case TRC_OPT_PIPELINE:
-      if (value < TRC_PIPE_WAVEFRONT || value > TRC_PIPE_QUEUE) return fail(TRC_ERR_INVALID, "bad pipeline");
+      if (value < TRC_PIPE_WAVEFRONT || value > TRC_PIPE_AUTO) return fail(TRC_ERR_INVALID, "bad pipeline");
       c->pipeline = value; return TRC_OK;
     case TRC_OPT_RECORD_HITS:
       c->record_hits = value ? 1 : 0; return TRC_OK;
@@ -344,7 +408,7 @@ int trc_upload_scene(trc_ctx* c, const void* objects, uint32_t count) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->nobj = 0;
-  rc = upload_packed(c->scene_d, c->scene_cap, c->sc, objs, tris, false);
+  rc = upload_packed(c->scene_d, c->scene_cap, c->sc, objs, tris, false, &c->big);
   if (rc != TRC_OK) return rc;
   c->objs_h.swap(objs);
   c->tris_h.swap(tris);
@@ -363,7 +427,7 @@ int trc_update_object(trc_ctx* c, uint32_t index, const float matrix[16], const 
   fill_axis_normals(d);
   // stream-ordered like the reference's cudaMemcpy on the default stream (Renderer.cpp:224)
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return upload_packed(c->scene_d, c->scene_cap, c->sc, c->objs_h, c->tris_h, true);
+  return upload_packed(c->scene_d, c->scene_cap, c->sc, c->objs_h, c->tris_h, true, &c->big);
 }
 
 int trc_raytrace1(trc_ctx* c, const trc_camera* cam) {
@@ -372,9 +436,13 @@ int trc_raytrace1(trc_ctx* c, const trc_camera* cam) {
   HIP_TRY(hipSetDevice(c->device));
   if (c->record_hits) { int rc = ensure_hit_buffers(c); if (rc) return rc; }
   FrameParams fp = make_params(c, cam, 0);
-  int rc = begin_timing(c); if (rc) return rc;
-  if (c->record_hits) launch_raytrace1(fp, c->ldr, c->hit_id, c->hit_t, c->hit_pos, c->hit_nor, c->stream);
-  else launch_raytrace1(fp, c->ldr, nullptr, nullptr, nullptr, nullptr, c->stream);
+  int rc = ensure_big_mesh_buffers(c); if (rc) return rc;
+  BigMeshPass bmp = big_mesh_pass(c);
+  const BigMeshPass* pass = c->big.empty() ? nullptr : &bmp;
+  if (pass) { fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = c->npix; }
+  rc = begin_timing(c); if (rc) return rc;
+  if (c->record_hits) launch_raytrace1(fp, c->ldr, c->hit_id, c->hit_t, c->hit_pos, c->hit_nor, c->counters, pass, c->stream);
+  else launch_raytrace1(fp, c->ldr, nullptr, nullptr, nullptr, nullptr, c->counters, pass, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
   return end_timing(c);
@@ -392,11 +460,20 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
   HIP_TRY(hipSetDevice(c->device));
   FrameParams fp = make_params(c, cam, seed);
   const uint32_t last_iter = iter_first + (n_iters - 1) * iter_stride;
-  if (c->pipeline == TRC_PIPE_WAVEFRONT || c->pipeline == TRC_PIPE_COMPACTED) {
-    int rc = ensure_wavefront_state(c, c->pipeline == TRC_PIPE_COMPACTED); if (rc) return rc;
+  // TRC_PIPE_AUTO: the work queue, unless a big mesh makes the per-bounce brute-force pass worth a launch
+  const int pipeline = c->pipeline != TRC_PIPE_AUTO ? c->pipeline : (c->big.empty() ? TRC_PIPE_QUEUE : TRC_PIPE_COMPACTED);
+  BigMeshPass bmp = {};
+  const BigMeshPass* pass = nullptr;
+  if (pipeline == TRC_PIPE_WAVEFRONT || pipeline == TRC_PIPE_COMPACTED) {
+    int rc = ensure_wavefront_state(c, pipeline == TRC_PIPE_COMPACTED); if (rc) return rc;
+    rc = ensure_big_mesh_buffers(c); if (rc) return rc;
+    if (!c->big.empty()) {
+      bmp = big_mesh_pass(c); pass = &bmp;
+      fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = c->npix;
+    }
   }
   uint32_t chunk_iters = 0;
-  if (c->pipeline == TRC_PIPE_QUEUE) {
+  if (pipeline == TRC_PIPE_QUEUE) {
     // iterations per chunk: what fits the staging budget (at least one), paths per chunk < 2^31
     const size_t per_iter = 3ull * c->npix;
     size_t fit = ((size_t)c->stage_mb << 20) / (sizeof(float) * per_iter);
@@ -418,20 +495,20 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
     }
   }
   int rc = begin_timing(c); if (rc) return rc;
-  if (c->pipeline == TRC_PIPE_QUEUE) {
+  if (pipeline == TRC_PIPE_QUEUE) {
     for (uint32_t done = 0; done < n_iters; done += chunk_iters) {
       const uint32_t n = (n_iters - done < chunk_iters) ? n_iters - done : chunk_iters;
       launch_queue(fp, iter_first + done * iter_stride, iter_stride, n, c->film, c->stage, c->next_task,
                    c->resident_blocks, c->counters, c->stream);
     }
-  } else if (c->pipeline == TRC_PIPE_FUSED) {
+  } else if (pipeline == TRC_PIPE_FUSED) {
     launch_fused(fp, iter_first, iter_stride, n_iters, c->film, c->counters, c->stream);
   } else {
-    const bool compact = c->pipeline == TRC_PIPE_COMPACTED;
+    const bool compact = pipeline == TRC_PIPE_COMPACTED;
     for (uint32_t k = 0; k < n_iters; ++k)
       launch_wavefront_iteration(fp, iter_first + k * iter_stride, compact, c->state[0],
                                  compact ? c->state[1] : c->state[0], c->queue_count,
-                                 c->film, c->counters, c->stream);
+                                 c->film, c->counters, pass, c->stream);
   }
   HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
   launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
@@ -649,7 +726,7 @@ void raytrace1(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
     return;
   }
   FrameParams fp = legacy_params(w, h, campos, A, B, C, 0.0f, 0.0f, ls, sceneSize, 0);
-  launch_raytrace1(fp, pbo_out, nullptr, nullptr, nullptr, nullptr, nullptr);   // default stream, as the reference
+  launch_raytrace1(fp, pbo_out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);   // default stream, as the reference
 }
 
 void pathtrace(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
