@@ -37,6 +37,23 @@ PEAK_FP32_TFLOPS = 157.3       # MI355X FP32 vector peak (packed FMA), MI355X_MI
 PEAK_FP32_UNFUSED_TFLOPS = 65.5  # measured (tools/micro/inst_cost.hip): v_mul_f32 / v_add_f32 issue every ~2.4
                                  # cycles per wave64 per SIMD at 8 waves -> 64 * 1024 SIMDs * 2.4 GHz / 2.4
 PEAK_HBM_GBS = 8000.0
+N_SIMD = 1024                    # 256 CUs x 4
+VALU_ISSUE_CYCLES = 2.17         # measured (tools/micro/clock_probe.hip): shader-clock cycles one SIMD needs per
+                                 # wave64 v_mul_f32 / v_add_f32, the cheapest VALU class (v_fma_f32, v_cmp: ~4)
+
+
+def measured_valu_mix():
+    """VALU wave-instructions per 64 live segments of k_queue on this workload, from the latest committed
+    rocprofv3 PMC pass (tools/pmc_fused.sh -> profiles/*_pmc_k_queue.json: SQ_INSTS_VALU / segments * 64)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", "*_pmc_k_queue.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return float(d["derived"]["valu_insts_per_64_segments"]), os.path.basename(files[-1])
+    except (KeyError, ValueError):
+        return None, None
 
 
 def measured_hbm_traffic():
@@ -94,7 +111,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pipeline", type=int, default=3, help="0 wavefront, 1 compacted, 2 fused, 3 work queue (default)")
+    ap.add_argument("--pipeline", type=int, default=3, help="0 wavefront, 1 compacted, 2 fused, 3 work queue (default), 4 auto (= 3 on this scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -177,7 +194,7 @@ def main():
         flop = seg_per_launch * FLOP_PER_SEGMENT + paths_per_launch * FLOP_PER_PATH
         achieved = flop / (k_ms * 1e-3) / 1e12
         kernel_name = {0: "k_bounce<false> (+k_raygen)", 1: "k_bounce<true> (+k_raygen)", 2: "k_fused",
-                       3: "k_queue (+memset, k_accumulate)"}[args.pipeline]
+                       3: "k_queue (+memset, k_accumulate)", 4: "k_queue (+memset, k_accumulate)"}[args.pipeline]
         out = {
             "metric": "Mpath-segments/s, Cornell box 512x512 path trace (mode 2), 300 iterations",
             "value": round(value, 2),
@@ -193,7 +210,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "cornell_box_512x512_mode2_300it", "width": W, "height": H,
                        "iterations_per_gpu": ITERS, "path_depth": 5, "rng": "philox4x32-10, reference reuse",
-                       "pipeline": ["wavefront", "compacted", "fused", "work-queue"][args.pipeline],
+                       "pipeline": ["wavefront", "compacted", "fused", "work-queue", "work-queue"][args.pipeline],
                        "parallelism": f"sample-index x{world}, one RCCL film sum-reduce per step" if world > 1 else "single GPU",
                        "live_segments_per_step_per_gpu": int(seg_per_launch),
                        "segments_per_path": round(seg_per_launch / max(paths_per_launch, 1), 4)},
@@ -217,8 +234,23 @@ def main():
                 "hbm_peak_GBs": PEAK_HBM_GBS,
             },
         }
-        if args.pipeline == 3:
+        if args.pipeline in (3, 4):
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_hbm_traffic()
+        if args.pipeline in (2, 3, 4) and cnt.get("shader_mhz"):
+            # FP32 VALU utilisation (the north_star's figure of merit): issue cycles the kernel's VALU
+            # instructions need at the best rate the SIMD has, over the cycles it ran -- instruction count
+            # from the committed PMC pass, shader clock measured live by the kernel's own wavefronts.
+            mhz = cnt["shader_mhz"]
+            out["roofline"]["shader_mhz"] = round(mhz, 1)
+            out["roofline"]["peak_unfused_at_clock"] = round(64 * N_SIMD * mhz * 1e6 / VALU_ISSUE_CYCLES / 1e12, 2)
+            out["roofline"]["frac_unfused_at_clock"] = round(achieved / out["roofline"]["peak_unfused_at_clock"], 4)
+            per64, src = measured_valu_mix()
+            if per64 and args.pipeline != 2:
+                insts_per_simd = per64 * seg_per_launch / 64.0 / N_SIMD
+                cycles = k_ms * 1e-3 * mhz * 1e6
+                out["roofline"]["valu_insts_per_64_segments"] = per64
+                out["roofline"]["valu_insts_source"] = src
+                out["roofline"]["valu_issue_utilisation"] = round(insts_per_simd * VALU_ISSUE_CYCLES / cycles, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -95,6 +95,11 @@ typedef struct trc_counters {
   uint64_t live_segments;   /* closest-hit evaluations for live paths (raytrace.cu:119-127) */
   uint64_t paths;           /* camera rays generated (pixels x iterations) */
   uint64_t tri_tests;       /* ray-triangle tests executed (Ray.inl:173) */
+  /* persistent path kernels (TRC_PIPE_QUEUE, TRC_PIPE_FUSED): sum over their wavefronts of the
+   * shader-clock cycles and of the constant 100 MHz reference ticks between a wavefront's first and
+   * last instruction; 100 * wave_cycles / wave_ref_ticks = the shader clock in MHz the kernel ran at */
+  uint64_t wave_cycles;
+  uint64_t wave_ref_ticks;
 } trc_counters;
 
 /* ---- life cycle (replaces Renderer::initCUDAMemory/freeCUDAMemory, Renderer.cpp:94-110) -- */

@@ -46,7 +46,8 @@ class Camera(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [("live_segments", C.c_uint64), ("paths", C.c_uint64), ("tri_tests", C.c_uint64)]
+    _fields_ = [("live_segments", C.c_uint64), ("paths", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("wave_cycles", C.c_uint64), ("wave_ref_ticks", C.c_uint64)]
 
 
 def lib_path():
@@ -243,7 +244,9 @@ class Tracer:
     def counters(self):
         c = Counters()
         self._check(self.L.trc_get_counters(self.ctx, C.byref(c)))
-        return dict(live_segments=int(c.live_segments), paths=int(c.paths), tri_tests=int(c.tri_tests))
+        return dict(live_segments=int(c.live_segments), paths=int(c.paths), tri_tests=int(c.tri_tests),
+                    wave_cycles=int(c.wave_cycles), wave_ref_ticks=int(c.wave_ref_ticks),
+                    shader_mhz=(100.0 * c.wave_cycles / c.wave_ref_ticks) if c.wave_ref_ticks else None)
 
     def reset_counters(self):
         self._check(self.L.trc_reset_counters(self.ctx))

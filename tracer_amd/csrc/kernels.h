@@ -41,6 +41,8 @@ struct DeviceCounters {
   unsigned long long live_segments;
   unsigned long long paths;
   unsigned long long tri_tests;
+  unsigned long long wave_cycles;      // persistent kernels: sum of clock64() spans of their wavefronts
+  unsigned long long wave_ref_ticks;   // ... and of wall_clock64() (100 MHz) spans
 };
 
 // ---- big meshes (scene.h: kBigMeshTris): brute-force pass in front of a closest-hit kernel ------

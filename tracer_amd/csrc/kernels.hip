@@ -405,6 +405,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
   f3 col = splat3(0.0f);
   uint32_t live = 0, tt = 0;
+  const unsigned long long clk0 = clock64(), ref0 = wall_clock64();
 
   while (true) {
     if (!done && need_new) {
@@ -431,6 +432,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
   count_add(&counters->live_segments, (unsigned long long)live);
   count_add(&counters->tri_tests, (unsigned long long)tt);
   count_add(&counters->paths, valid ? (unsigned long long)n_iters : 0ull);
+  if (lane_id() == 0) {
+    atomicAdd(&counters->wave_cycles, clock64() - clk0);
+    atomicAdd(&counters->wave_ref_ticks, wall_clock64() - ref0);
+  }
 }
 
 
@@ -473,6 +478,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
   f3 col = splat3(1.0f);
   uint32_t live = 0, tt = 0, paths = 0;
+  const unsigned long long clk0 = clock64(), ref0 = wall_clock64();
 
   while (true) {
     const unsigned long long need = __ballot(!have);
@@ -538,6 +544,10 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
   count_add(&counters->live_segments, (unsigned long long)live);
   count_add(&counters->tri_tests, (unsigned long long)tt);
   count_add(&counters->paths, (unsigned long long)paths);
+  if (lane == 0) {
+    atomicAdd(&counters->wave_cycles, clock64() - clk0);
+    atomicAdd(&counters->wave_ref_ticks, wall_clock64() - ref0);
+  }
 }
 
 // film[pixel] += stage[0][pixel] + stage[1][pixel] + ... strictly in that order (raytrace.cu:170);

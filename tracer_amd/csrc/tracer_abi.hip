@@ -596,6 +596,7 @@ int trc_get_counters(trc_ctx* c, trc_counters* out) {
   HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   out->live_segments = h.live_segments; out->paths = h.paths; out->tri_tests = h.tri_tests;
+  out->wave_cycles = h.wave_cycles; out->wave_ref_ticks = h.wave_ref_ticks;
   return TRC_OK;
 }
 
