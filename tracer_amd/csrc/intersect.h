@@ -49,16 +49,20 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
 // (func_geometric.inl:243, func_exponential.inl:151); hipcc's IEEE sqrtf + division cost 28 VALU
 // instructions, most of them range scaling and special-case fix-ups. The sequences below were
 // compared with those IEEE results for ALL 2^32 inputs on gfx950 (tools/micro/crmath_check.hip):
-//   sqrt:  v_sqrt, v_rsq, one fma residual, one fma correction -- exact for every x >= 2^-102
+//   sqrt:  y = v_rsq(x), s = x * y, one fma residual, one fma correction by y/2 -- exact for every x >= 2^-102
 //   1/x :  v_rcp + one Newton step                             -- exact for every normal |x| < 2^126
+//   a/d :  r = that 1/d, q = a * r, two fma residual corrections: hipcc's own expansion of `/` without its
+//          v_div_scale / v_div_fixup steps, i.e. the same arithmetic wherever those steps do nothing;
+//          compared with `/` on 2^34 random pairs with 2^-40 <= |a|, |d| < 2^40 (no mismatch)
 // Outside those ranges (zero vectors, denormals, inf, NaN) the wave takes the IEEE path; the
 // choice is made per wavefront with a ballot, so the result is bit-identical either way.
 // `need` = this lane's result is observable (dead / masked lanes must not force the slow path).
 __device__ __forceinline__ float cr_rsqrt(float s, bool need) {
   const bool ok = (__float_as_uint(s) - 0x0D000000u) < (0x7E800000u - 0x0D000000u);   // 2^-101 <= s < 2^126
   if (__ballot(need & !ok) == 0ull) {
-    const float q0 = __builtin_amdgcn_sqrtf(s);
-    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
+    const float y = __builtin_amdgcn_rsqf(s);
+    const float q0 = s * y;
+    const float h = 0.5f * y;
     const float q = __builtin_fmaf(__builtin_fmaf(-q0, q0, s), h, q0);      // correctly rounded sqrt(s)
     const float r0 = __builtin_amdgcn_rcpf(q);
     return __builtin_fmaf(__builtin_fmaf(-q, r0, 1.0f), r0, r0);            // correctly rounded 1/q
@@ -68,8 +72,9 @@ __device__ __forceinline__ float cr_rsqrt(float s, bool need) {
 __device__ __forceinline__ float cr_sqrt(float s, bool need) {
   const bool ok = (__float_as_uint(s) - 0x0D000000u) < (0x7F800000u - 0x0D000000u);   // 2^-101 <= s < inf
   if (__ballot(need & !ok) == 0ull) {
-    const float q0 = __builtin_amdgcn_sqrtf(s);
-    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
+    const float y = __builtin_amdgcn_rsqf(s);
+    const float q0 = s * y;
+    const float h = 0.5f * y;
     return __builtin_fmaf(__builtin_fmaf(-q0, q0, s), h, q0);
   }
   return sqrtf(s);
@@ -121,10 +126,38 @@ __device__ __forceinline__ float hit_triangle(const Ray& ray, const DevTri& tri,
   return t;
 }
 
-// Slab test shared by CUBE (Ray.inl:121-127) and MESH (Ray.inl:161-167).
-__device__ __forceinline__ bool slab(const Ray& ray, f3 bmin, f3 bmax, float& tNear, float& tFar) {
-  f3 tMin = (bmin - ray.pos) / ray.dir;
-  f3 tMax = (bmax - ray.pos) / ray.dir;
+// Slab test shared by CUBE (Ray.inl:121-127) and MESH (Ray.inl:161-167). The six IEEE divisions share three
+// reciprocals: q = a / d as a * RN(1/d) plus two residual corrections (see above), taken by the whole
+// wavefront when every lane that matters has 2^-40 <= |a|, |d| < 2^40 for all nine operands (|d| <= 1 for
+// a normalised direction, |a| <= |bound| + |origin|); otherwise the wavefront divides with `/`.
+__device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }   // v_min3_f32
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32
+__device__ __forceinline__ float div_core(float a, float d, float r) {
+  float q = a * r;
+  q = __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+  return __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+}
+__device__ __forceinline__ bool slab(const Ray& ray, f3 bmin, f3 bmax, float& tNear, float& tFar, bool need) {
+  const f3 a0 = bmin - ray.pos, a1 = bmax - ray.pos;
+  const f3 d = ray.dir;
+  f3 tMin, tMax;
+  const float lo = __builtin_fminf(__builtin_fminf(min3f(__builtin_fabsf(a0.x), __builtin_fabsf(a0.y), __builtin_fabsf(a0.z)),
+                                                   min3f(__builtin_fabsf(a1.x), __builtin_fabsf(a1.y), __builtin_fabsf(a1.z))),
+                                   min3f(__builtin_fabsf(d.x), __builtin_fabsf(d.y), __builtin_fabsf(d.z)));
+  const float hi = __builtin_fmaxf(max3f(__builtin_fabsf(a0.x), __builtin_fabsf(a0.y), __builtin_fabsf(a0.z)),
+                                   max3f(__builtin_fabsf(a1.x), __builtin_fabsf(a1.y), __builtin_fabsf(a1.z)));
+  const bool ok = (lo >= 0x1p-40f) & (hi < 0x1p40f);
+  if (__ballot(need & !ok) == 0ull) {
+    const float rx0 = __builtin_amdgcn_rcpf(d.x), ry0 = __builtin_amdgcn_rcpf(d.y), rz0 = __builtin_amdgcn_rcpf(d.z);
+    const float rx = __builtin_fmaf(__builtin_fmaf(-d.x, rx0, 1.0f), rx0, rx0);
+    const float ry = __builtin_fmaf(__builtin_fmaf(-d.y, ry0, 1.0f), ry0, ry0);
+    const float rz = __builtin_fmaf(__builtin_fmaf(-d.z, rz0, 1.0f), rz0, rz0);
+    tMin = mk3(div_core(a0.x, d.x, rx), div_core(a0.y, d.y, ry), div_core(a0.z, d.z, rz));
+    tMax = mk3(div_core(a1.x, d.x, rx), div_core(a1.y, d.y, ry), div_core(a1.z, d.z, rz));
+  } else {
+    tMin = a0 / d;
+    tMax = a1 / d;
+  }
   f3 t1 = gmin(tMin, tMax);
   f3 t2 = gmax(tMin, tMax);
   tNear = gmax(gmax(t1.x, t1.y), t1.z);
@@ -327,7 +360,7 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, c
 __device__ __forceinline__ void cube(Closest& c, const Ray& ray, bool live, const DevXform& xf, const DevCubeExtra& ex) {
   const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
-  const bool hit = slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar);
+  const bool hit = slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar, live);
   const float th = tNear > 0.0f ? tNear : tFar;
   const f3 p = r.pos + r.dir * th;
   // six wave-uniform candidates: select from the last test to the first
@@ -348,7 +381,7 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, cons
                                      const DevMeshExtra& ex, const DevScene& sc, uint32_t slot, uint32_t& tri_tests) {
   const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
-  const bool pass = live && slab(r, ex.bmin, ex.bmax, tNear, tFar);
+  const bool pass = slab(r, ex.bmin, ex.bmax, tNear, tFar, live) && live;
   f3 bn;
   float tb;
   if (sc.mesh_keys != nullptr && ex.big_slot != kNotBig) {

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t m
   const DevMeshExtra& ex = fp.sc.meshes[mesh_index];
   const Ray r = to_object_space(ray, xf.mi, live);                       // exactly as mesh() in intersect.h
   float tNear, tFar;
-  const bool pass = live && slab(r, ex.bmin, ex.bmax, tNear, tFar);
+  const bool pass = slab(r, ex.bmin, ex.bmax, tNear, tFar, live) && live;
   // a ray with a NaN coordinate passes the slab test (Ray.inl:167 is written with `>` and `<`) and then
   // fails every triangle, because each t it produces is NaN; it gets the "no hit" key without being queued.
   const bool finite = (r.pos.x == r.pos.x) & (r.pos.y == r.pos.y) & (r.pos.z == r.pos.z) &
