@@ -298,10 +298,10 @@ __device__ __forceinline__ void consider(Closest& c, const Ray& ray, float t, ui
 struct Held { bool any; float t; f3 p; uint32_t k; };
 
 template <bool SPHERE>
-__device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const DevXform* __restrict__ xf, Held& h) {
+__device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h) {
   if (__ballot(h.any) == 0ull) return;
   if (h.any) {
-    const DevXform& x = xf[h.k];                                // per-lane gather (a handful of distinct records)
+    const DevXform& x = xg[h.k];                                // per-lane gather (a handful of distinct records)
     const Affine m = x.m;
     f3 wn = x.nor_y;                                            // planes: object +y (Ray.inl:156, :62)
     if (SPHERE) wn = normalize_dev(xform_dir(m, normalize_dev(h.p, true)), true);   // Ray.inl:116, :62
@@ -310,9 +310,9 @@ __device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const Dev
   h.any = false;
 }
 template <bool SPHERE>
-__device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform* __restrict__ xf, Held& h,
+__device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h,
                                      bool cand, float t, f3 p, uint32_t k) {
-  if (__ballot(cand & h.any) != 0ull) flush_held<SPHERE>(c, ray, xf, h);
+  if (__ballot(cand & h.any) != 0ull) flush_held<SPHERE>(c, ray, xg, h);
   if (cand) { h.any = true; h.t = t; h.p = p; h.k = k; }
 }
 
@@ -320,7 +320,7 @@ __device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform*
 // always object +y -> DevXform::nor_y. Only t > 0 competes (Ray.inl:72).
 template <int K>
 __device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf,
-                                       uint32_t first, Held& h) {
+                                       const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[first + k].mi, live);    // Ray.inl:88
@@ -329,7 +329,7 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, co
     const float tp = -r[k].pos.y / r[k].dir.y;
     const f3 p = r[k].pos + tp * r[k].dir;
     const bool in = (p.x < 0.5f) & (p.z < 0.5f) & (p.x > -0.5f) & (p.z > -0.5f);
-    hold<false>(c, ray, xf, h, live & in & (tp > 0.0f), tp, p, first + k);
+    hold<false>(c, ray, xg, h, live & in & (tp > 0.0f), tp, p, first + k);
   }
 }
 
@@ -337,7 +337,7 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, co
 // then Ray.inl:62 normalize(M * (n, 0)) -- both only for a held candidate (flush_held).
 template <int K>
 __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf,
-                                        uint32_t first, Held& h) {
+                                        const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[first + k].mi, live);
@@ -351,7 +351,7 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, c
     const float q = cr_sqrt(0.25f - m2, hit);
     const float th = (l2 > 0.25f) ? s - q : s + q;
     const f3 p = r[k].pos + r[k].dir * th;
-    hold<true>(c, ray, xf, h, hit & (th > 0.0f), th, p, first + k);
+    hold<true>(c, ray, xg, h, hit & (th > 0.0f), th, p, first + k);
   }
 }
 
@@ -409,20 +409,24 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, cons
 
 // Wave-convergent (see the header comment).
 // `slot`: this ray's row in the key table of the big-mesh passes (unused while sc.mesh_keys is null).
-__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevScene& sc, uint32_t& tri_tests, uint32_t slot = 0u) {
+// `gather`: where the per-lane matrix gathers of the held candidates read the DevXform table from -- a copy
+// of sc.xf in LDS when the kernel made one (k_queue), else sc.xf itself.
+__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevScene& sc, uint32_t& tri_tests, uint32_t slot = 0u,
+                                           const DevXform* __restrict__ gather = nullptr) {
   Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
   const DevXform* __restrict__ xf = sc.xf;
+  const DevXform* __restrict__ xg = gather ? gather : sc.xf;
   uint32_t i = 0;
   Held h; h.any = false; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u;
   TRC_MARK("planes");
-  for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, live, xf, i, h);
-  if (i < sc.n_plane) planes<1>(c, ray, live, xf, i, h);
-  flush_held<false>(c, ray, xf, h);
-  xf += sc.n_plane;
+  for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, live, xf, xg, i, h);
+  if (i < sc.n_plane) planes<1>(c, ray, live, xf, xg, i, h);
+  flush_held<false>(c, ray, xg, h);
+  xf += sc.n_plane; xg += sc.n_plane;
   TRC_MARK("spheres");
-  for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, live, xf, i, h);
-  if (i < sc.n_sphere) spheres<1>(c, ray, live, xf, i, h);
-  flush_held<true>(c, ray, xf, h);
+  for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, live, xf, xg, i, h);
+  if (i < sc.n_sphere) spheres<1>(c, ray, live, xf, xg, i, h);
+  flush_held<true>(c, ray, xg, h);
   xf += sc.n_sphere;
   TRC_MARK("cubes");
   for (i = 0; i < sc.n_cube; ++i) cube(c, ray, live, xf[i], sc.cubes[i]);

@@ -69,8 +69,9 @@ __device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx
 enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE = 3 };
 
 __device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uint32_t pixel, uint32_t iter, int depth,
-                                           Ray& ray, f3& col, uint32_t& tri_tests, uint32_t slot = 0u) {
-  Hit hit = closest_hit(ray, live, fp.sc, tri_tests, slot);
+                                           Ray& ray, f3& col, uint32_t& tri_tests, uint32_t slot = 0u,
+                                           const DevXform* __restrict__ gather = nullptr) {
+  Hit hit = closest_hit(ray, live, fp.sc, tri_tests, slot, gather);
   if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
   const DevMaterial& o = fp.sc.mats[hit.id];
@@ -456,6 +457,10 @@ constexpr uint32_t kGrab = 512;
 struct alignas(16) RaySlot { float px, py, pz, dx; float dy, dz; uint32_t pixel, itk; };
 static_assert(sizeof(RaySlot) == 32, "RaySlot");
 constexpr uint32_t kRing = 128;
+#ifndef TRC_GATHER_MAX
+#define TRC_GATHER_MAX 16
+#endif
+constexpr uint32_t kGatherMax = TRC_GATHER_MAX;   // DevXform records k_queue keeps in LDS (2 KB)
 
 #ifndef TRC_QUEUE_WAVES
 #define TRC_QUEUE_WAVES 5          // resident waves per SIMD the kernel is compiled for
@@ -466,6 +471,16 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
                                                     uint32_t* __restrict__ next_task, DeviceCounters* counters) {
   __shared__ RaySlot s_ring[kMaxWavesPerBlock * kRing];
   RaySlot* __restrict__ ring = s_ring + (threadIdx.x >> 6) * kRing;
+  // The plane / sphere records that held candidates gather per lane (intersect.h: flush_held), copied to LDS once.
+  __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];
+  const uint32_t n_gather = fp.sc.n_plane + fp.sc.n_sphere;
+  const DevXform* gather = nullptr;
+  if (n_gather <= kGatherMax) {
+    const uint32_t n_dw = n_gather * (uint32_t)(sizeof(DevXform) / 4);
+    for (uint32_t i = threadIdx.x; i < n_dw; i += kBlock) ((uint32_t*)s_xf)[i] = ((const uint32_t*)fp.sc.xf)[i];
+    __syncthreads();
+    gather = s_xf;
+  }
   const uint32_t total = fp.npix * n_iters;
   const unsigned lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
       ring_count -= taken;
     }
     if (__ballot(have) == 0ull) break;
-    const int res = bounce_step(fp, have, pixel, iter, depth, ray, col, tt);
+    const int res = bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, gather);
     TRC_MARK("bounce_done");
     if (res == STEP_CONTINUE) {
       ++live; ++depth;
