@@ -107,6 +107,12 @@ typedef struct trc_counters {
 int trc_create(int device, uint32_t width, uint32_t height, void* stream, trc_ctx** out);
 int trc_destroy(trc_ctx* ctx);
 int trc_set_option(trc_ctx* ctx, int option, int value);
+/* Image-tile partition (no counterpart in the reference, which renders every pixel on one GPU): from now on
+ * trc_raytrace1 / trc_pathtrace render only image rows [row0, row0 + rows) and leave the rest of the film,
+ * LDR and hit buffers untouched; rows == 0 returns to the whole image. The RNG is keyed by the absolute
+ * pixel, so a tile holds exactly the values the full frame has there and disjoint tiles rendered on
+ * different GPUs over zeroed films combine with the same single sum-reduce as the sample partition. */
+int trc_set_tile(trc_ctx* ctx, uint32_t row0, uint32_t rows);
 
 /* ---- scene (replaces Renderer::initScene / updateScene, Renderer.cpp:112-151, :221-225) -- */
 int trc_upload_scene(trc_ctx* ctx, const void* objects, uint32_t count);

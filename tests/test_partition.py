@@ -37,7 +37,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, total_iters, w, h, seed, out_dir):
+def _worker(rank, world, port, total_iters, w, h, seed, out_dir, by_tile=False):
     import torch
     import torch.distributed as dist
     from oracle.pyoracle import Oracle
@@ -48,7 +48,13 @@ def _worker(rank, world, port, total_iters, w, h, seed, out_dir):
     cam = o.camera_default(w, h)
     first, stride, count = multi.rank_iterations(total_iters, rank, world)
     film = np.zeros((w * h, 3), np.float32)
-    if count:
+    if by_tile:
+        # image-tile partition: this rank's band of rows of every iteration, zero elsewhere (the oracle
+        # renders whole frames, so the band is cut out of one; on the GPU trc_set_tile renders only it)
+        y0, y1 = multi.tile_rows(h, rank, world)
+        whole = o.pathtrace(s, w, h, cam, seed, 1, total_iters, want_pbo=False)["film"].reshape(h, w, 3)
+        film = film.reshape(h, w, 3); film[y0:y1] = whole[y0:y1]; film = film.reshape(w * h, 3)
+    elif count:
         film = o.pathtrace(s, w, h, cam, seed, first, count, iter_stride=stride, film=film, want_pbo=False)["film"]
     t = torch.from_numpy(film)
     multi.reduce_film(t, dist, 0)
@@ -74,3 +80,15 @@ def test_two_rank_render_equals_single_rank(oracle_c, tmp_path):
     a = oracle_c.pathtrace(s, w, h, cam, seed, 1, 4, iter_stride=2)["film"]
     b = oracle_c.pathtrace(s, w, h, cam, seed, 2, 3, iter_stride=2)["film"]
     assert got.tobytes() == (a + b).astype(np.float32).tobytes()
+
+
+def test_three_rank_tile_partition_equals_single_rank(oracle_c, tmp_path):
+    """Disjoint bands of rows over zeroed films, one sum-reduce: bit for bit the single-rank film."""
+    import torch.multiprocessing as mp
+    w, h, total, seed = 40, 31, 3, 8
+    port = _free_port()
+    mp.spawn(_worker, args=(3, port, total, w, h, seed, str(tmp_path), True), nprocs=3, join=True)
+    got = np.load(tmp_path / "film.npy")
+    s = oracle_c.scene_create(0)
+    ref = oracle_c.pathtrace(s, w, h, oracle_c.camera_default(w, h), seed, 1, total)["film"]
+    assert got.tobytes() == ref.tobytes()

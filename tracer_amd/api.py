@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "trc_create", "trc_destroy", "trc_set_option", "trc_upload_scene", "trc_update_object",
     "trc_raytrace1", "trc_pathtrace", "trc_reset_film", "trc_tonemap", "trc_read_film",
     "trc_write_film", "trc_read_ldr", "trc_read_hits", "trc_synchronize", "trc_film_device_ptr",
-    "trc_bind_film", "trc_get_counters", "trc_reset_counters", "trc_last_render_ms", "trc_last_kernel_ms",
+    "trc_bind_film", "trc_set_tile", "trc_get_counters", "trc_reset_counters", "trc_last_render_ms", "trc_last_kernel_ms",
     "trc_last_error_string", "trc_version", "pathtrace", "raytrace1",
 ]
 # every symbol include/tracer_host.h declares
@@ -108,6 +108,7 @@ def load_library():
     L.trc_synchronize.argtypes = [vp]
     L.trc_film_device_ptr.argtypes = [vp, C.POINTER(vp)]
     L.trc_bind_film.argtypes = [vp, vp]
+    L.trc_set_tile.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.trc_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.trc_reset_counters.argtypes = [vp]
     L.trc_last_render_ms.argtypes = [vp, C.POINTER(f32)]
@@ -177,6 +178,10 @@ class Tracer:
 
     def set_pipeline(self, pipe):
         self._check(self.L.trc_set_option(self.ctx, OPT_PIPELINE, pipe))
+
+    def set_tile(self, row0, rows):
+        """Render only image rows [row0, row0 + rows) from now on (rows == 0: the whole image)."""
+        self._check(self.L.trc_set_tile(self.ctx, row0, rows))
 
     def set_stage_mb(self, mb):
         self._check(self.L.trc_set_option(self.ctx, OPT_STAGE_MB, int(mb)))

@@ -11,7 +11,11 @@ namespace trc {
 // segment -> SGPRs).
 struct FrameParams {
   uint32_t w, h, npix;
-  UDiv div_w, div_npix;     // index -> (x, y), task -> (iteration, pixel) without an integer division
+  // The pixels this launch renders: [pix0, pix0 + ntile), whole rows (trc_set_tile; the whole image by
+  // default). Kernels number their work 0 .. ntile-1 ("slot") and address the film, the RNG and the
+  // camera with pixel = pix0 + slot, so a tile holds exactly the values the full frame has there.
+  uint32_t pix0, ntile;
+  UDiv div_w, div_npix, div_tile;   // pixel -> (x, y); % npix of raytrace.cu:155; task -> (iteration, slot)
   float fw, fh, rcp_w, rcp_h;   // (float)w, (float)h and their correctly rounded reciprocals (div_by_uniform)
   f3 campos, A, B, C;       // raytrace.cu:192
   f3 nA, nB;                // normalize(A), normalize(B) of raytrace.cu:94, hoisted to the host
@@ -24,6 +28,7 @@ struct FrameParams {
 inline void set_dims(FrameParams& fp, uint32_t w, uint32_t h) {
   fp.w = w; fp.h = h; fp.npix = w * h;
   fp.div_w = make_udiv(w); fp.div_npix = make_udiv(fp.npix);
+  fp.pix0 = 0; fp.ntile = fp.npix; fp.div_tile = fp.div_npix;
   fp.fw = (float)w; fp.fh = (float)h; fp.rcp_w = 1.0f / fp.fw; fp.rcp_h = 1.0f / fp.fh;
 }
 
@@ -63,6 +68,10 @@ struct BigMeshPass {
   unsigned long long* keys;
   unsigned grid_blocks;
 };
+
+inline void set_tile(FrameParams& fp, uint32_t row0, uint32_t rows) {
+  fp.pix0 = row0 * fp.w; fp.ntile = rows * fp.w; fp.div_tile = make_udiv(fp.ntile);
+}
 
 // mode 1 (raytrace.cu:29-62). hit_* may be null; bmp is null when the scene has no big mesh.
 void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, float* hit_t,

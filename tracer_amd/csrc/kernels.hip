@@ -99,11 +99,12 @@ __global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* 
                                                      int32_t* __restrict__ hit_id, float* __restrict__ hit_t,
                                                      float* __restrict__ hit_pos, float* __restrict__ hit_nor,
                                                      DeviceCounters* counters) {
-  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
-  const bool valid = idx < fp.npix;          // no early return: closest_hit is wave-convergent
+  const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t idx = fp.pix0 + slot;
+  const bool valid = slot < fp.ntile;        // no early return: closest_hit is wave-convergent
   Ray ray = primary_ray(fp, idx);
   uint32_t tt = 0;
-  Hit hit = closest_hit(ray, valid, fp.sc, tt, idx);
+  Hit hit = closest_hit(ray, valid, fp.sc, tt, slot);
   if (counters) count_add(&counters->tri_tests, (unsigned long long)tt);
   if (!valid) return;
   const f3 lightDir = mk3((float)0.267261, (float)0.801784, (float)0.534522);
@@ -161,12 +162,12 @@ __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t m
                                                      const uint32_t* __restrict__ count_in, MeshRayQueue q,
                                                      unsigned long long* __restrict__ keys) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t n_in = (SOURCE == 1 && count_in) ? *count_in : fp.npix;
+  const uint32_t n_in = (SOURCE == 1 && count_in) ? *count_in : fp.ntile;
   if (blockIdx.x * kBlock >= n_in) return;
   bool live = i < n_in;
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
   if (SOURCE == 0) {
-    ray = primary_ray(fp, i);
+    ray = primary_ray(fp, fp.pix0 + i);
   } else {
     live = live && cur.pixel[i] >= 0;
     if (live) { ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]); ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]); }
@@ -315,20 +316,21 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter, PathState st,
                                                   uint32_t* __restrict__ queue_count,
                                                   float* __restrict__ film, DeviceCounters* counters) {
-  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;      // slot
   if (idx == 0) {
-    queue_count[0] = fp.npix;
+    queue_count[0] = fp.ntile;
 #pragma unroll
     for (int d = 1; d <= kPathDepth; ++d) queue_count[d] = 0;
   }
-  const bool valid = idx < fp.npix;
+  const bool valid = idx < fp.ntile;
+  const uint32_t pixel = fp.pix0 + idx;
   if (valid) {
-    Ray ray = camera_sample(fp, idx, iter);
+    Ray ray = camera_sample(fp, pixel, iter);
     st.px[idx] = ray.pos.x; st.py[idx] = ray.pos.y; st.pz[idx] = ray.pos.z;
     st.dx[idx] = ray.dir.x; st.dy[idx] = ray.dir.y; st.dz[idx] = ray.dir.z;
     st.cr[idx] = 1.0f; st.cg[idx] = 1.0f; st.cb[idx] = 1.0f;           // raytrace.cu:99
-    st.pixel[idx] = (int32_t)idx;                                     // :101
-    if (iter == 1) { film[3 * idx] = 0.0f; film[3 * idx + 1] = 0.0f; film[3 * idx + 2] = 0.0f; } // :103
+    st.pixel[idx] = (int32_t)pixel;                                   // :101
+    if (iter == 1) { film[3 * pixel] = 0.0f; film[3 * pixel + 1] = 0.0f; film[3 * pixel + 2] = 0.0f; } // :103
   }
   count_add(&counters->paths, valid ? 1ull : 0ull);
 }
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
                                                   uint32_t* __restrict__ count_out,
                                                   float* __restrict__ film, DeviceCounters* counters) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t n_in = COMPACT ? *count_in : fp.npix;
+  const uint32_t n_in = COMPACT ? *count_in : fp.ntile;
   if (blockIdx.x * kBlock >= n_in) return;                            // whole block past the queue
   int32_t pixel = (i < n_in) ? cur.pixel[i] : -1;
   const bool active = pixel >= 0;                                     // raytrace.cu:119-124
@@ -394,8 +396,8 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
 __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                  uint32_t n_iters, float* __restrict__ film,
                                                  DeviceCounters* counters) {
-  const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
-  const bool valid = pixel < fp.npix;
+  const uint32_t pixel = fp.pix0 + blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = blockIdx.x * kBlock + threadIdx.x < fp.ntile;
   f3 acc = splat3(0.0f);
   if (valid) acc = mk3(film[3 * pixel], film[3 * pixel + 1], film[3 * pixel + 2]);
   uint32_t k = 0;                 // iterations of this call already accumulated
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
     __syncthreads();
     gather = s_xf;
   }
-  const uint32_t total = fp.npix * n_iters;
+  const uint32_t total = fp.ntile * n_iters;
   const unsigned lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: task ids this wave has reserved
@@ -516,7 +518,8 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
         const bool gen = lane < take;
         TRC_MARK("regen");
         uint32_t g_pixel;
-        const uint32_t g_itk = udivmod(gen ? pool_next + lane : 0u, fp.div_npix, g_pixel);
+        const uint32_t g_itk = udivmod(gen ? pool_next + lane : 0u, fp.div_tile, g_pixel);
+        g_pixel += fp.pix0;
         const Ray g = camera_sample(fp, g_pixel, iter_first + g_itk * iter_stride, gen);
         if (gen) {
           RaySlot& o = ring[(ring_head + ring_count + lane) & (kRing - 1u)];
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
     } else if (res != STEP_IDLE) {
       ++live;
       if (res == STEP_LIGHT) {                                        // black endings add nothing
-        float* dst = stage + 3ull * ((unsigned long long)itk * fp.npix + pixel);
+        float* dst = stage + 3ull * ((unsigned long long)itk * fp.ntile + (pixel - fp.pix0));
         dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
       }
       have = false;
@@ -600,7 +603,7 @@ static void launch_big_mesh_passes(const FrameParams& fp, PathState cur, const u
     if (tiles_per_seg < 16u) tiles_per_seg = 16u;
     const uint32_t n_segs = (n_tiles + tiles_per_seg - 1) / tiles_per_seg;
     (void)hipMemsetAsync(bmp.q.count, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(grid_for(fp.npix)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(grid_for(fp.ntile)), dim3(kBlock), 0, stream,
                        fp, m.mesh_index, cur, count_in, bmp.q, bmp.keys);
     hipLaunchKernelGGL(k_mesh_brute, dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
                        bmp.q, fp.sc.hot + m.hot_first, fp.sc.tris + m.tri_first, m.tri_count, n_tiles,
@@ -612,14 +615,14 @@ void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, flo
                       float* hit_pos, float* hit_nor, DeviceCounters* counters, const BigMeshPass* bmp,
                       hipStream_t stream) {
   if (bmp) launch_big_mesh_passes<0>(fp, PathState{}, nullptr, *bmp, stream);
-  hipLaunchKernelGGL(k_raytrace1, dim3(grid_for(fp.npix)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(k_raytrace1, dim3(grid_for(fp.ntile)), dim3(kBlock), 0, stream,
                      fp, ldr, hit_id, hit_t, hit_pos, hit_nor, counters);
 }
 
 void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compact,
                                 PathState cur, PathState next, uint32_t* queue_count,
                                 float* film, DeviceCounters* counters, const BigMeshPass* bmp, hipStream_t stream) {
-  const dim3 grid(grid_for(fp.npix)), block(kBlock);
+  const dim3 grid(grid_for(fp.ntile)), block(kBlock);
   hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter, cur, queue_count, film, counters);
   for (int d = 0; d < kPathDepth; ++d) {
     if (bmp) launch_big_mesh_passes<1>(fp, cur, compact ? queue_count + d : nullptr, *bmp, stream);
@@ -636,14 +639,14 @@ void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compa
 
 void launch_fused(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
                   float* film, DeviceCounters* counters, hipStream_t stream) {
-  hipLaunchKernelGGL(k_fused, dim3(grid_for(fp.npix)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(k_fused, dim3(grid_for(fp.ntile)), dim3(kBlock), 0, stream,
                      fp, iter_first, iter_stride, n_iters, film, counters);
 }
 
 void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
                   float* film, float* stage, uint32_t* next_task, unsigned resident_blocks,
                   DeviceCounters* counters, hipStream_t stream) {
-  const size_t paths = (size_t)fp.npix * n_iters;
+  const size_t paths = (size_t)fp.ntile * n_iters;
   (void)hipMemsetAsync(stage, 0, sizeof(float) * 3ull * paths, stream);
   (void)hipMemsetAsync(next_task, 0, sizeof(uint32_t), stream);
   unsigned blocks = (unsigned)((paths + kBlock - 1) / kBlock);
@@ -651,8 +654,8 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
   if (blocks > resident_blocks) blocks = resident_blocks;
   hipLaunchKernelGGL(k_queue, dim3(blocks), dim3(kBlock), 0, stream,
                      fp, iter_first, iter_stride, n_iters, stage, next_task, counters);
-  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(3u * fp.npix)), dim3(kBlock), 0, stream,
-                     film, (const float*)stage, fp.npix, n_iters, iter_first == 1u ? 1 : 0);
+  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(3u * fp.ntile)), dim3(kBlock), 0, stream,
+                     film + 3ull * fp.pix0, (const float*)stage, fp.ntile, n_iters, iter_first == 1u ? 1 : 0);
 }
 
 void launch_tonemap(const float* film, uint32_t npix, float iters, uint32_t* ldr, hipStream_t stream) {

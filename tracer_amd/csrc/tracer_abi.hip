@@ -49,6 +49,7 @@ struct trc_ctx {
   int pipeline = TRC_PIPE_AUTO;
   int stage_mb = 2048;
   int record_hits = 1;
+  uint32_t tile_row0 = 0, tile_rows = 0;   // trc_set_tile; rows == 0: the whole image
 
   // scene: one device allocation [xforms | cube extras | mesh extras | materials | triangles]
   void* scene_d = nullptr;
@@ -154,6 +155,7 @@ void affine_from_mat4(Affine& a, const float m[16]) {
 FrameParams make_params(const trc_ctx* c, const trc_camera* cam, uint64_t seed) {
   FrameParams fp;
   set_dims(fp, c->w, c->h);
+  if (c->tile_rows) set_tile(fp, c->tile_row0, c->tile_rows);
   fp.campos = ld3(cam->campos); fp.A = ld3(cam->A); fp.B = ld3(cam->B); fp.C = ld3(cam->C);
   fp.nA = normalize(fp.A);       // raytrace.cu:94 evaluates these per thread; same IEEE ops here
   fp.nB = normalize(fp.B);
@@ -399,6 +401,14 @@ int trc_set_option(trc_ctx* c, int option, int value) {
   }
 }
 
+int trc_set_tile(trc_ctx* c, uint32_t row0, uint32_t rows) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  if (rows == 0) { c->tile_row0 = 0; c->tile_rows = 0; return TRC_OK; }
+  if (row0 >= c->h || rows > c->h - row0) return fail(TRC_ERR_INVALID, "trc_set_tile: rows outside the image");
+  c->tile_row0 = row0; c->tile_rows = rows;
+  return TRC_OK;
+}
+
 int trc_upload_scene(trc_ctx* c, const void* objects, uint32_t count) {
   if (!c) return fail(TRC_ERR_INVALID, "null context");
   if (!objects || count == 0) return fail(TRC_ERR_INVALID, "trc_upload_scene: empty scene");
@@ -475,9 +485,9 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
   uint32_t chunk_iters = 0;
   if (pipeline == TRC_PIPE_QUEUE) {
     // iterations per chunk: what fits the staging budget (at least one), paths per chunk < 2^31
-    const size_t per_iter = 3ull * c->npix;
+    const size_t per_iter = 3ull * fp.ntile;
     size_t fit = ((size_t)c->stage_mb << 20) / (sizeof(float) * per_iter);
-    const size_t cap31 = 0x7FFFFFFFull / c->npix;
+    const size_t cap31 = 0x7FFFFFFFull / fp.ntile;
     if (fit > cap31) fit = cap31;
     if (fit < 1) fit = 1;
     chunk_iters = (uint32_t)(fit < n_iters ? fit : n_iters);

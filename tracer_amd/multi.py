@@ -33,11 +33,23 @@ def reduce_film(film, dist, dst=0):
     return film
 
 
-def render_partitioned(tracer, cam, seed, total_iters, film, rank, world, dist):
+def render_partitioned(tracer, cam, seed, total_iters, film, rank, world, dist, by_tile=False, height=None):
     """Render this rank's share of `total_iters` iterations into `film` (a torch tensor bound to
-    the tracer with Tracer.bind_film), sum-reduce to rank 0 and tonemap there."""
-    first, stride, count = rank_iterations(total_iters, rank, world)
+    the tracer with Tracer.bind_film), sum-reduce to rank 0 and tonemap there. The share is a set of
+    sample indices (default) or, with by_tile, a band of image rows rendered for every iteration; the
+    films are zeroed first, so the same sum assembles disjoint tiles."""
     film.zero_()
+    if by_tile:
+        y0, y1 = tile_rows(height, rank, world)
+        if y1 > y0:
+            tracer.set_tile(y0, y1 - y0)
+            tracer.pathtrace(cam, seed, 1, total_iters)
+            tracer.set_tile(0, 0)
+        reduce_film(film, dist, 0)
+        if rank == 0:
+            tracer.tonemap(total_iters)
+        return film
+    first, stride, count = rank_iterations(total_iters, rank, world)
     if count:
         tracer.pathtrace(cam, seed, first, count, iter_stride=stride)
     reduce_film(film, dist, 0)
