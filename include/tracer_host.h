@@ -24,6 +24,18 @@ typedef struct trc_scene trc_scene;
  *              (0,-2,0)                                                  [BASELINE.json configs[4]]
  * data_dir holds icosahedron.obj (the reference's data/icosahedron.obj). */
 int trc_scene_cornell(int variant, int param, const char* data_dir, trc_scene** out);
+/* Scene description file (the reference compiles its scene in, main.cpp:274-396). One
+ * statement per line, `#` comments; transforms are applied in the order written through the same
+ * Object::scale / rotate / translate calls main.cpp makes (tracer_amd/data/cornell.scene lists exactly
+ * those calls and yields the same Object[] bit for bit):
+ *   camera [fov F] [zoom Z] [focal D] [lens R] [rotate RX RY]
+ *   mesh NAME plane|cube|sphere | mesh NAME obj PATH | mesh NAME icosphere BASE LEVELS
+ *   object MESH   followed by   scale S | scale X Y Z | rotate DEGREES X Y Z | translate X Y Z |
+ *                               color R G B | emit E | brdf B | ior N | material diff|trans|mirr
+ * cam_out (may be NULL) receives the camera frame for an aspect_w x aspect_h image. On failure returns
+ * TRC_ERR_INVALID with "file:line: reason" in err (may be NULL). */
+int trc_scene_load(const char* path, uint32_t aspect_w, uint32_t aspect_h, trc_scene** out, trc_camera* cam_out,
+                   char* err, uint32_t err_len);
 void trc_scene_free(trc_scene* scene);
 uint32_t trc_scene_size(const trc_scene* scene);
 /* Object::Object[] in the reference's host layout; pass to trc_upload_scene. */

@@ -71,6 +71,35 @@ def test_cornell_scene_equals_oracle(product_lib, oracle_c, variant, param):
         assert p["material"] == d["color"].tobytes() + np.array([d["emit"], d["brdf"], d["n"]], np.float32).tobytes() + struct.pack("i", d["mat_type"])
 
 
+def test_scene_file_reproduces_the_hard_coded_scene(product_lib, tmp_path):
+    """tracer_amd/data/cornell.scene lists main.cpp:274-396's calls; loading it gives the same
+    Object[] (matrices, inverses, materials, meshes) and camera frame as the built-in scene, bit for bit."""
+    import tracer_amd as ta
+    built_in = ta.Scene(0)
+    loaded = ta.Scene(path=os.path.join(REPO, "tracer_amd", "data", "cornell.scene"), aspect=(512, 512))
+    assert loaded.size == built_in.size == 9
+    a = _flatten_objects(built_in.raw_objects(), 9); b = _flatten_objects(loaded.raw_objects(), 9)
+    for i in range(9):
+        assert a[i] == b[i], i
+    assert bytes(loaded.camera) == bytes(ta.camera_default(512, 512))
+    # variants of the grammar, and errors with file:line
+    p = tmp_path / "s.scene"
+    p.write_text("camera zoom -13 focal 13 lens 0.5 rotate 0.2 0.1\nmesh base obj %s\nmesh ball icosphere base 2\n"
+                 "object ball\n scale 3\n translate 0 -2 0\n color 1 1 0\n material trans\n ior 1.5\n"
+                 % os.path.join(REPO, "tracer_amd", "data", "icosahedron.obj"))
+    sc = ta.Scene(path=str(p), aspect=(64, 32))
+    o = _flatten_objects(sc.raw_objects(), 1)[0]
+    ball = ta.Scene(2, 2)
+    ref = _flatten_objects(ball.raw_objects(), 7)[6]
+    assert o["matrix"] == ref["matrix"] and o["verts"] == ref["verts"] and o["faces"] == ref["faces"] and o["bmax"] == ref["bmax"]
+    assert abs(sc.camera.lensRadius - 0.5) < 1e-7
+    for text, where in (("object nothing\n", ":1:"), ("mesh a plane\nobject a\n scale 1 2\n", ":3:"),
+                        ("mesh a plane\n translate 0 0 0\n", ":2:"), ("mesh a obj missing.obj\n", ":1:"), ("", "no objects")):
+        p.write_text(text)
+        with pytest.raises(ta.TracerError, match=where):
+            ta.Scene(path=str(p))
+
+
 def test_scene_edits_equal_oracle(product_lib, oracle_c):
     import tracer_amd as ta
     sc = ta.Scene(0); s = oracle_c.scene_create(0)

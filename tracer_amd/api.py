@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
 ]
 # every symbol include/tracer_host.h declares
 HOST_SYMBOLS = [
-    "trc_scene_cornell", "trc_scene_free", "trc_scene_size", "trc_scene_objects",
+    "trc_scene_cornell", "trc_scene_load", "trc_scene_free", "trc_scene_size", "trc_scene_objects",
     "trc_scene_translate", "trc_scene_rotate", "trc_scene_scale", "trc_scene_add_obj",
     "trc_scene_set_material", "trc_camera_default", "trc_write_ppm", "trc_write_pfm",
 ]
@@ -123,6 +123,7 @@ def load_library():
     for name in HOST_SYMBOLS:
         getattr(L, name).restype = i32
     L.trc_scene_cornell.argtypes = [i32, i32, C.c_char_p, C.POINTER(vp)]
+    L.trc_scene_load.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(Camera), C.c_char_p, C.c_uint32]
     L.trc_scene_free.argtypes = [vp]; L.trc_scene_free.restype = None
     L.trc_scene_size.argtypes = [vp]; L.trc_scene_size.restype = u32
     L.trc_scene_objects.argtypes = [vp]; L.trc_scene_objects.restype = vp
@@ -271,9 +272,20 @@ class Scene:
     """Host-side scene (include/tracer_host.h): the reference's Cornell box built through the
     Object/Mesh API mirror. No GPU involved."""
 
-    def __init__(self, variant=0, param=0, data_dir=None):
+    def __init__(self, variant=0, param=0, data_dir=None, path=None, aspect=(512, 512)):
+        """Scene(variant, param): the built-in Cornell variants; Scene(path=..., aspect=(w, h)): a scene
+        description file (include/tracer_host.h: trc_scene_load), whose camera is then in self.camera."""
         self.L = load_library()
         self.h = C.c_void_p()
+        self.camera = None
+        if path is not None:
+            cam = Camera()
+            err = C.create_string_buffer(512)
+            rc = self.L.trc_scene_load(os.fsencode(path), aspect[0], aspect[1], C.byref(self.h), C.byref(cam), err, 512)
+            if rc != 0:
+                raise TracerError(f"trc_scene_load: {err.value.decode(errors='replace')}")
+            self.camera = cam
+            return
         rc = self.L.trc_scene_cornell(variant, param, (data_dir or DATA_DIR).encode(), C.byref(self.h))
         if rc != 0:
             raise TracerError(f"trc_scene_cornell failed ({rc})")

@@ -7,6 +7,10 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -95,6 +99,133 @@ int trc_scene_cornell(int variant, int param, const char* data_dir, trc_scene** 
     Object::scale(ball, 3.0f / Mesh::icosphereRadius(param));      // world radius 3 at every level
     Object::translate(ball, mk3(0.0f, -2.0f, 0.0f));
     ball.material.color = mk3(1.0f, 1.0f, 0.0f);
+  }
+  *out = s;
+  return TRC_OK;
+}
+
+// ---- scene description files (the reference's scene is compiled in, main.cpp:274-396) ----
+// One statement per line, `#` starts a comment. Transforms are applied in the order written, through
+// the same Object::scale / rotate / translate calls main.cpp makes, so a file that lists main.cpp's
+// calls reproduces its Object[] bit for bit (tracer_amd/data/cornell.scene, tests/test_host_mirror.py).
+//   camera [fov F] [zoom Z] [focal D] [lens R] [rotate RX RY]     ThirdPersonCamera set-up of main.cpp:275-279
+//   mesh NAME plane|cube|sphere                                   Mesh::newGeometry
+//   mesh NAME obj PATH                                            Mesh::loadObj, PATH relative to the file
+//   mesh NAME icosphere BASE LEVELS                               Mesh::icosphere of mesh BASE
+//   object MESH                                                   Object::newObject; the statements below edit it
+//   scale S | scale X Y Z      rotate DEGREES X Y Z      translate X Y Z
+//   color R G B    emit E    brdf B    ior N    material diff|trans|mirr
+int trc_scene_load(const char* path, uint32_t aspect_w, uint32_t aspect_h, trc_scene** out, trc_camera* cam_out,
+                   char* err, uint32_t err_len) {
+  auto fail = [&](const std::string& msg) {
+    if (err && err_len) { snprintf(err, err_len, "%s", msg.c_str()); }
+    return (int)TRC_ERR_INVALID;
+  };
+  if (!out || !path) return fail("null argument");
+  *out = nullptr;
+  std::ifstream in(path);
+  if (!in) return fail(std::string("cannot open ") + path);
+  std::string dir(path);
+  const size_t slash = dir.find_last_of('/');
+  dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+  trc_scene* s = new trc_scene;
+  s->objs.reserve(64);
+  std::map<std::string, Mesh::Mesh*> meshes;
+  ThirdPersonCamera cam;
+  cam.setFOV(30.0f);                                   // FOV, common.h:40
+  if (aspect_w && aspect_h) cam.setAspect(aspect_w, aspect_h);
+  float rot_x = 0.0f, rot_y = 0.0f;
+  Object::Object* cur = nullptr;
+  std::string line;
+  int lineno = 0;
+  auto bad = [&](const std::string& what) {
+    delete s;
+    return fail(std::string(path) + ":" + std::to_string(lineno) + ": " + what);
+  };
+  while (std::getline(in, line)) {
+    ++lineno;
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line.erase(hash);
+    std::istringstream ls(line);
+    std::string kw;
+    if (!(ls >> kw)) continue;
+    std::vector<std::string> a;
+    for (std::string t; ls >> t;) a.push_back(t);
+    auto num = [&](size_t i, float& v) {
+      if (i >= a.size()) return false;
+      char* end = nullptr;
+      v = strtof(a[i].c_str(), &end);
+      return end && *end == 0 && end != a[i].c_str();
+    };
+    if (kw == "camera") {
+      for (size_t i = 0; i < a.size();) {
+        float v, w;
+        if (a[i] == "rotate") { if (!num(i + 1, v) || !num(i + 2, w)) return bad("camera rotate RX RY"); rot_x = v; rot_y = w; i += 3; continue; }
+        if (!num(i + 1, v)) return bad("camera " + a[i] + " needs a number");
+        if (a[i] == "fov") cam.setFOV(v);
+        else if (a[i] == "zoom") cam.zoom(v);
+        else if (a[i] == "focal") cam.m_focalDist = v;
+        else if (a[i] == "lens") cam.m_lensRadius = v;
+        else return bad("unknown camera parameter " + a[i]);
+        i += 2;
+      }
+    } else if (kw == "mesh") {
+      if (a.size() < 2) return bad("mesh NAME KIND ...");
+      if (meshes.count(a[0])) return bad("mesh " + a[0] + " defined twice");
+      Mesh::Mesh* m = nullptr;
+      if (a[1] == "plane") m = Mesh::newGeometry(Mesh::PLANE);
+      else if (a[1] == "cube") m = Mesh::newGeometry(Mesh::CUBE);
+      else if (a[1] == "sphere") m = Mesh::newGeometry(Mesh::SPHERE);
+      else if (a[1] == "obj") {
+        if (a.size() != 3) return bad("mesh NAME obj PATH");
+        std::string e;
+        m = Mesh::loadObj(a[2][0] == '/' ? a[2] : dir + "/" + a[2], &e);
+        if (!m) return bad(e);
+      } else if (a[1] == "icosphere") {
+        float lv;
+        if (a.size() != 4 || !meshes.count(a[2]) || !num(3, lv) || lv < 0.0f || lv > 10.0f || lv != (float)(int)lv)
+          return bad("mesh NAME icosphere BASE LEVELS (0..10)");
+        if (meshes[a[2]]->type != Mesh::MESH) return bad("icosphere base must be a triangle mesh");
+        m = Mesh::icosphere(*meshes[a[2]], (int)lv);
+      } else return bad("unknown mesh kind " + a[1]);
+      if (!m) return bad("could not create mesh " + a[0]);
+      meshes[a[0]] = s->own(m);
+    } else if (kw == "object") {
+      if (a.size() != 1 || !meshes.count(a[0])) return bad("object MESH (a mesh defined above)");
+      cur = &s->add(meshes[a[0]]);
+    } else {
+      if (!cur) return bad(kw + " before the first object");
+      float x, y, z, w;
+      if (kw == "scale") {
+        if (a.size() == 1 && num(0, x)) Object::scale(*cur, x);                             // Object.inl:81
+        else if (a.size() == 3 && num(0, x) && num(1, y) && num(2, z)) Object::scale(*cur, mk3(x, y, z));   // :86
+        else return bad("scale S | scale X Y Z");
+      } else if (kw == "rotate") {
+        if (a.size() != 4 || !num(0, w) || !num(1, x) || !num(2, y) || !num(3, z)) return bad("rotate DEGREES X Y Z");
+        Object::rotate(*cur, angleAxis(w, mk3(x, y, z)));
+      } else if (kw == "translate") {
+        if (a.size() != 3 || !num(0, x) || !num(1, y) || !num(2, z)) return bad("translate X Y Z");
+        Object::translate(*cur, mk3(x, y, z));
+      } else if (kw == "color") {
+        if (a.size() != 3 || !num(0, x) || !num(1, y) || !num(2, z)) return bad("color R G B");
+        cur->material.color = mk3(x, y, z);
+      } else if (kw == "emit" || kw == "brdf" || kw == "ior") {
+        if (a.size() != 1 || !num(0, x)) return bad(kw + " VALUE");
+        (kw == "emit" ? cur->material.emit : kw == "brdf" ? cur->material.brdf : cur->material.n) = x;
+      } else if (kw == "material") {
+        if (a.size() != 1) return bad("material diff|trans|mirr");
+        if (a[0] == "diff") cur->material.type = Material::DIFF;
+        else if (a[0] == "trans") cur->material.type = Material::TRANS;
+        else if (a[0] == "mirr") cur->material.type = Material::MIRR;
+        else return bad("material diff|trans|mirr");
+      } else return bad("unknown statement " + kw);
+    }
+  }
+  if (s->objs.empty()) { lineno = 0; return bad("no objects"); }
+  if (cam_out) {
+    cam.rotate(rot_x, rot_y);
+    cam.update();
+    cameraFrame(cam, cam_out);
   }
   *out = s;
   return TRC_OK;
