@@ -114,9 +114,19 @@ def test_config5_icosphere_1310720_triangles_1024x1024(ta, oracle_c):
     assert sub(hits["nor"]).tobytes() == ref["nor"].reshape(256, -1).tobytes()
     assert sub(hits["pos"]).tobytes() == ref["pos"].reshape(256, -1).tobytes()
     assert (ref["ids"] == 6).sum() >= 20 and (hits["ids"] == 6).mean() > 0.1
+    # the same frame through the BVH (TRC_OPT_MESH_ACCEL): every pixel identical to the exhaustive loop's
+    tr.set_mesh_accel(True)
+    tr.raytrace1(cam)
+    accel = tr.read_hits()
+    for k in ("ids", "ts", "pos", "nor"):
+        assert accel[k].tobytes() == hits[k].tobytes(), k
+    tr.set_mesh_accel(False)
     tr.pathtrace(cam, 2, 1, 1)                       # AUTO -> compacted + brute-force pass
     a = tr.read_film()
     tr.set_pipeline(ta.PIPE_WAVEFRONT)
+    tr.pathtrace(cam, 2, 1, 1)
+    assert tr.read_film().tobytes() == a.tobytes()
+    tr.set_pipeline(ta.PIPE_AUTO); tr.set_mesh_accel(True)
     tr.pathtrace(cam, 2, 1, 1)
     assert tr.read_film().tobytes() == a.tobytes()
     assert np.isfinite(a).all()

@@ -1,5 +1,5 @@
 """configs[4]: Cornell walls + one tessellated icosphere MESH, brute-force closest hit.
-    python3 tools/mesh_bench.py [level=8] [w=1024] [h=1024] [mode2_iters=1] [pipeline=-1 (library default)]
+    python3 tools/mesh_bench.py [level=8] [w=1024] [h=1024] [mode2_iters=1] [pipeline=-1 (library default)] [accel=0]
 Prints mode-1 and mode-2 kernel time and ray-triangle tests/s."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +10,7 @@ w = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 pipe = int(sys.argv[5]) if len(sys.argv) > 5 else -1
+accel = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 t0 = time.time()
 sc = ta.Scene(2, level)
 print(f"scene built in {time.time()-t0:.2f} s (level {level}: {20 * 4**level} triangles)", flush=True)
@@ -21,6 +22,8 @@ t0 = time.time()
 tr.upload_scene(sc.objects_ptr, sc.size)
 print(f"scene uploaded in {time.time()-t0:.2f} s", flush=True)
 tr.set_record_hits(True)
+tr.set_mesh_accel(bool(accel))
+print("big meshes:", "BVH (TRC_OPT_MESH_ACCEL = 1)" if accel else "every face (the reference's loop)", flush=True)
 for rep in range(2):
     tr.reset_counters()
     tr.raytrace1(cam)

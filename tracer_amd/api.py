@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RNG_REFERENCE, RNG_DECORRELATED = 0, 1
 PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED, PIPE_QUEUE, PIPE_AUTO = 0, 1, 2, 3, 4
-OPT_RNG_MODE, OPT_PIPELINE, OPT_RECORD_HITS, OPT_STAGE_MB = 0, 1, 2, 3
+OPT_RNG_MODE, OPT_PIPELINE, OPT_RECORD_HITS, OPT_STAGE_MB, OPT_MESH_ACCEL = 0, 1, 2, 3, 4
 
 # every symbol include/tracer_abi.h declares
 ABI_SYMBOLS = [
@@ -183,6 +183,10 @@ class Tracer:
     def set_tile(self, row0, rows):
         """Render only image rows [row0, row0 + rows) from now on (rows == 0: the whole image)."""
         self._check(self.L.trc_set_tile(self.ctx, row0, rows))
+
+    def set_mesh_accel(self, on):
+        """Big meshes: False = test every face (the reference's loop, default), True = BVH in front of the same test."""
+        self._check(self.L.trc_set_option(self.ctx, OPT_MESH_ACCEL, int(bool(on))))
 
     def set_stage_mb(self, mb):
         self._check(self.L.trc_set_option(self.ctx, OPT_STAGE_MB, int(mb)))

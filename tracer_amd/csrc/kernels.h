@@ -3,6 +3,7 @@
 #pragma once
 #include "scene.h"
 #include "pmath.h"
+#include "bvh.h"
 #include <hip/hip_runtime.h>
 
 namespace trc {
@@ -62,8 +63,10 @@ struct MeshRayQueue {
 // What the launchers need to run those passes: the scene's big meshes, the queue (reused mesh
 // after mesh, bounce after bounce: everything is stream-ordered), the key table
 // keys[big_slot * fp.sc.key_stride + slot] (== fp.sc.mesh_keys) and the size of the persistent grid.
+struct DevBvh { const BvhNode* nodes; const uint32_t* faces; BvhParams prm; };   // device arrays of one big mesh's hierarchy
 struct BigMeshPass {
   const BigMesh* big; uint32_t n_big;
+  const DevBvh* bvh;               // per big mesh, or null: exhaustive loop (the reference's behaviour)
   MeshRayQueue q;
   unsigned long long* keys;
   unsigned grid_blocks;

@@ -11,6 +11,7 @@
 #include "intersect.h"
 #include "shade.h"
 #include "rng.h"
+#include "bvh.h"
 
 #pragma clang fp contract(off)
 
@@ -312,6 +313,53 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
   }
 }
 
+// The same queue and key table, served by the bounding-volume hierarchy of bvh.h instead of the exhaustive
+// loop (TRC_OPT_MESH_ACCEL = 1): one ray per lane, a per-lane stack in LDS, the exact hit_triangle() for
+// every face of every leaf whose padded box the ray's line meets. See bvh.h for why that visits every face
+// the exhaustive loop could accept.
+__global__ __launch_bounds__(kBlock) void k_mesh_bvh(MeshRayQueue q, const BvhNode* __restrict__ nodes,
+                                                    const uint32_t* __restrict__ faces, const DevTri* __restrict__ tris,
+                                                    BvhParams prm, unsigned long long* __restrict__ keys) {
+  __shared__ uint32_t s_stack[kBvhMaxDepth][kBlock];
+  const uint32_t nq = *q.count;
+  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < nq; j += gridDim.x * kBlock) {
+    Ray r;
+    r.pos = mk3(q.ox[j], q.oy[j], q.oz[j]); r.dir = mk3(q.dx[j], q.dy[j], q.dz[j]);
+    const uint32_t slot = q.slot[j];
+    const f3 oc = r.pos - prm.centre;
+    const float reach = sqrtf(dot(oc, oc)) + prm.radius;
+    const float pad = kPadScale * prm.max_edge * prm.max_edge * (reach + prm.max_edge);
+    const float grow = pad + 1e-5f * reach;
+    const f3 inv = mk3(1.0f / r.dir.x, 1.0f / r.dir.y, 1.0f / r.dir.z);
+    unsigned long long best = kKeyNone;
+    float best_t = FLT_MAX;
+    int sp = 0;
+    s_stack[sp++][threadIdx.x] = 0u;
+    while (sp > 0) {
+      const BvhNode nd = nodes[s_stack[--sp][threadIdx.x]];
+      // the ray's LINE against the grown box; every comparison is written so that a NaN keeps the node
+      const f3 t0 = (nd.bmin - splat3(grow) - r.pos) * inv, t1 = (nd.bmax + splat3(grow) - r.pos) * inv;
+      const float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+      const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+      if (tn > tf || tf < -2.0f * pad || tn > best_t + 2.0f * pad) continue;
+      if (nd.count == 0u) {
+        if (sp + 2 <= kBvhMaxDepth) { s_stack[sp++][threadIdx.x] = nd.first; s_stack[sp++][threadIdx.x] = nd.first + 1u; }
+        continue;
+      }
+      for (uint32_t k = 0; k < nd.count; ++k) {
+        const uint32_t face = faces[nd.first + k];
+        f3 n;
+        const float t = hit_triangle(r, tris[face], n);                // Ray.inl:189-226, exactly
+        if (t > 0.0f && t < FLT_MAX) {                                  // Ray.inl:174
+          const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | face;
+          if (key < best) { best = key; best_t = t; }
+        }
+      }
+    }
+    if (best != kKeyNone) atomicMin(&keys[slot], best);
+  }
+}
+
 // ---- wavefront pipelines -------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter, PathState st,
                                                   uint32_t* __restrict__ queue_count,
@@ -605,6 +653,12 @@ static void launch_big_mesh_passes(const FrameParams& fp, PathState cur, const u
     (void)hipMemsetAsync(bmp.q.count, 0, sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(grid_for(fp.ntile)), dim3(kBlock), 0, stream,
                        fp, m.mesh_index, cur, count_in, bmp.q, bmp.keys);
+    if (bmp.bvh && bmp.bvh[b].nodes) {
+      hipLaunchKernelGGL(k_mesh_bvh, dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
+                         bmp.q, bmp.bvh[b].nodes, bmp.bvh[b].faces, fp.sc.tris + m.tri_first, bmp.bvh[b].prm,
+                         bmp.keys + (size_t)b * fp.sc.key_stride);
+      continue;
+    }
     hipLaunchKernelGGL(k_mesh_brute, dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
                        bmp.q, fp.sc.hot + m.hot_first, fp.sc.tris + m.tri_first, m.tri_count, n_tiles,
                        tiles_per_seg, n_segs, bmp.keys + (size_t)b * fp.sc.key_stride);

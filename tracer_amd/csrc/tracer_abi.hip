@@ -49,6 +49,7 @@ struct trc_ctx {
   int pipeline = TRC_PIPE_AUTO;
   int stage_mb = 2048;
   int record_hits = 1;
+  int mesh_accel = 0;                      // TRC_OPT_MESH_ACCEL
   uint32_t tile_row0 = 0, tile_rows = 0;   // trc_set_tile; rows == 0: the whole image
 
   // scene: one device allocation [xforms | cube extras | mesh extras | materials | triangles]
@@ -81,6 +82,7 @@ struct trc_ctx {
   float* mesh_queue_mem = nullptr;
   MeshRayQueue mesh_queue = {};
   unsigned brute_blocks = 0;
+  std::vector<DevBvh> bvh;             // per big mesh, built on first use with TRC_OPT_MESH_ACCEL = 1
 
   DeviceCounters* counters = nullptr;
 };
@@ -111,6 +113,29 @@ int ensure_hit_buffers(trc_ctx* c) {
   return TRC_OK;
 }
 
+void free_bvh(trc_ctx* c) {
+  for (DevBvh& b : c->bvh) { (void)hipFree((void*)b.nodes); (void)hipFree((void*)b.faces); }
+  c->bvh.clear();
+}
+
+// Build (host, median split) and upload the hierarchy of every big mesh; meshes live in object space, so
+// trc_update_object leaves them valid and only trc_upload_scene discards them.
+int ensure_bvh(trc_ctx* c) {
+  if (!c->mesh_accel || c->bvh.size() == c->big.size()) return TRC_OK;
+  free_bvh(c);
+  for (const BigMesh& m : c->big) {
+    std::vector<BvhNode> nodes; std::vector<uint32_t> faces; BvhParams prm;
+    build_bvh(c->tris_h.data() + m.tri_first, m.tri_count, nodes, faces, prm);
+    DevBvh d; d.prm = prm; d.nodes = nullptr; d.faces = nullptr;
+    HIP_TRY(hipMalloc((void**)&d.nodes, nodes.size() * sizeof(BvhNode)));
+    c->bvh.push_back(d);
+    HIP_TRY(hipMalloc((void**)&c->bvh.back().faces, faces.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy((void*)c->bvh.back().nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((void*)c->bvh.back().faces, faces.data(), faces.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  return TRC_OK;
+}
+
 // Buffers of the big-mesh brute-force passes: key table (one row of npix keys per big mesh) and
 // the ray queue (npix entries: slot + 6 floats, and the counter).
 int ensure_big_mesh_buffers(trc_ctx* c) {
@@ -130,6 +155,7 @@ int ensure_big_mesh_buffers(trc_ctx* c) {
     q.dx = p + 4ull * c->npix; q.dy = p + 5ull * c->npix; q.dz = p + 6ull * c->npix;
     q.count = (uint32_t*)(p + 7ull * c->npix);
   }
+  { int rc = ensure_bvh(c); if (rc) return rc; }
   if (!c->brute_blocks) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
@@ -141,6 +167,7 @@ int ensure_big_mesh_buffers(trc_ctx* c) {
 BigMeshPass big_mesh_pass(const trc_ctx* c) {
   BigMeshPass b;
   b.big = c->big.data(); b.n_big = (uint32_t)c->big.size();
+  b.bvh = (c->mesh_accel && c->bvh.size() == c->big.size() && !c->bvh.empty()) ? c->bvh.data() : nullptr;
   b.q = c->mesh_queue; b.keys = c->mesh_keys; b.grid_blocks = c->brute_blocks;
   return b;
 }
@@ -375,6 +402,7 @@ int trc_destroy(trc_ctx* c) {
   free_dev(c->state_mem[0]); free_dev(c->state_mem[1]); free_dev(c->queue_count);
   free_dev(c->counters); free_dev(c->stage); free_dev(c->next_task);
   free_dev(c->mesh_keys); free_dev(c->mesh_queue_mem);
+  free_bvh(c);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -394,6 +422,9 @@ int trc_set_option(trc_ctx* c, int option, int value) {
       c->pipeline = value; return TRC_OK;
     case TRC_OPT_RECORD_HITS:
       c->record_hits = value ? 1 : 0; return TRC_OK;
+    case TRC_OPT_MESH_ACCEL:
+      if (value != 0 && value != 1) return fail(TRC_ERR_INVALID, "bad mesh acceleration mode");
+      c->mesh_accel = value; return TRC_OK;
     case TRC_OPT_STAGE_MB:
       if (value < 1) return fail(TRC_ERR_INVALID, "bad staging budget");
       c->stage_mb = value; return TRC_OK;
@@ -418,6 +449,7 @@ int trc_upload_scene(trc_ctx* c, const void* objects, uint32_t count) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->nobj = 0;
+  free_bvh(c);
   rc = upload_packed(c->scene_d, c->scene_cap, c->sc, objs, tris, false, &c->big);
   if (rc != TRC_OK) return rc;
   c->objs_h.swap(objs);
