@@ -81,13 +81,16 @@ void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, flo
                       float* hit_pos, float* hit_nor, DeviceCounters* counters, const BigMeshPass* bmp,
                       hipStream_t stream);
 
-// mode 2, wavefront pipelines: one iteration = raygen + kPathDepth bounce launches.
-// compact = false: state stays at slot == pixel, dead paths flagged (pixel plane = -1).
+// mode 2, wavefront pipelines: a chunk of `n_iters` iterations (iter_first, +stride, ...) in one launch
+// sequence = raygen + kPathDepth bounce launches over ntile * n_iters path slots + k_accumulate.
+// compact = false: state stays at its slot, dead paths flagged (pixel plane = -1).
 // compact = true : survivors are written densely into `next` behind a wave-ballot prefix sum;
 //                  queue_count[d] is the number of live paths entering bounce d.
-void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compact,
-                                PathState cur, PathState next, uint32_t* queue_count /*[kPathDepth+1]*/,
-                                float* film, DeviceCounters* counters, const BigMeshPass* bmp, hipStream_t stream);
+// cur / next hold ntile * n_iters entries each, stage 3 * ntile * n_iters floats.
+void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
+                            bool compact, PathState cur, PathState next, uint32_t* queue_count /*[kPathDepth+1]*/,
+                            float* film, float* stage, DeviceCounters* counters, const BigMeshPass* bmp,
+                            hipStream_t stream);
 
 // mode 2, fused persistent pipeline: all iterations of the call in one launch.
 void launch_fused(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,

@@ -159,11 +159,11 @@ constexpr unsigned long long kKeyNone = ((unsigned long long)0x7f7fffffu << 32) 
 // SOURCE 0: primary rays of mode 1 (slot = pixel). SOURCE 1: the live paths of a bounce pass
 // (slot = position in the path-state arrays; n_in from the queue counter when compacting).
 template <int SOURCE>
-__global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t mesh_index, PathState cur,
+__global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t mesh_index, uint32_t n_slots, PathState cur,
                                                      const uint32_t* __restrict__ count_in, MeshRayQueue q,
                                                      unsigned long long* __restrict__ keys) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t n_in = (SOURCE == 1 && count_in) ? *count_in : fp.ntile;
+  const uint32_t n_in = (SOURCE == 1 && count_in) ? *count_in : n_slots;
   if (blockIdx.x * kBlock >= n_in) return;
   bool live = i < n_in;
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
@@ -361,39 +361,49 @@ __global__ __launch_bounds__(kBlock) void k_mesh_bvh(MeshRayQueue q, const BvhNo
 }
 
 // ---- wavefront pipelines -------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter, PathState st,
-                                                  uint32_t* __restrict__ queue_count,
-                                                  float* __restrict__ film, DeviceCounters* counters) {
-  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;      // slot
+// The reference's structure (raytrace.cu:211-225): ray state in HBM, one launch per bounce. One launch
+// sequence carries a CHUNK of iterations at once -- slot = iteration_in_chunk * ntile + pixel_in_tile, so
+// a 512x512 image still gives every launch millions of paths -- and, as in the work-queue pipeline, a
+// path that reaches the light stores its radiance at stage[slot]; k_accumulate then adds a pixel's
+// samples in iteration order (raytrace.cu:170), which keeps the film bit-exact although the iterations
+// of a chunk run side by side. The `pixel` plane of the state holds the path's slot (-1 once it ended).
+__global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
+                                                  uint32_t n_slots, PathState st,
+                                                  uint32_t* __restrict__ queue_count, DeviceCounters* counters) {
+  const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;      // slot
   if (idx == 0) {
-    queue_count[0] = fp.ntile;
+    queue_count[0] = n_slots;
 #pragma unroll
     for (int d = 1; d <= kPathDepth; ++d) queue_count[d] = 0;
   }
-  const bool valid = idx < fp.ntile;
-  const uint32_t pixel = fp.pix0 + idx;
+  const bool valid = idx < n_slots;
   if (valid) {
-    Ray ray = camera_sample(fp, pixel, iter);
+    uint32_t s;
+    const uint32_t itk = udivmod(idx, fp.div_tile, s);
+    Ray ray = camera_sample(fp, fp.pix0 + s, iter_first + itk * iter_stride);
     st.px[idx] = ray.pos.x; st.py[idx] = ray.pos.y; st.pz[idx] = ray.pos.z;
     st.dx[idx] = ray.dir.x; st.dy[idx] = ray.dir.y; st.dz[idx] = ray.dir.z;
     st.cr[idx] = 1.0f; st.cg[idx] = 1.0f; st.cb[idx] = 1.0f;           // raytrace.cu:99
-    st.pixel[idx] = (int32_t)pixel;                                   // :101
-    if (iter == 1) { film[3 * pixel] = 0.0f; film[3 * pixel + 1] = 0.0f; film[3 * pixel + 2] = 0.0f; } // :103
+    st.pixel[idx] = (int32_t)idx;                                     // :101
   }
   count_add(&counters->paths, valid ? 1ull : 0ull);
 }
 
 template <bool COMPACT>
-__global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter, int depth,
+__global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
+                                                  uint32_t n_slots, int depth,
                                                   PathState cur, PathState next,
                                                   const uint32_t* __restrict__ count_in,
                                                   uint32_t* __restrict__ count_out,
-                                                  float* __restrict__ film, DeviceCounters* counters) {
+                                                  float* __restrict__ stage, DeviceCounters* counters) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t n_in = COMPACT ? *count_in : fp.ntile;
+  const uint32_t n_in = COMPACT ? *count_in : n_slots;
   if (blockIdx.x * kBlock >= n_in) return;                            // whole block past the queue
-  int32_t pixel = (i < n_in) ? cur.pixel[i] : -1;
-  const bool active = pixel >= 0;                                     // raytrace.cu:119-124
+  const int32_t task = (i < n_in) ? cur.pixel[i] : -1;
+  const bool active = task >= 0;                                      // raytrace.cu:119-124
+  uint32_t s = 0;
+  const uint32_t itk = udivmod(active ? (uint32_t)task : 0u, fp.div_tile, s);
+  const uint32_t pixel = fp.pix0 + s, iter = iter_first + itk * iter_stride;
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
   f3 col = splat3(0.0f);
   uint32_t tt = 0;
@@ -402,10 +412,11 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
     ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
     col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
   }
-  const int res = bounce_step(fp, active, active ? (uint32_t)pixel : 0u, iter, depth, ray, col, tt, i);
+  const int res = bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i);
   const bool cont = (res == STEP_CONTINUE);
   if (res == STEP_LIGHT) {                                            // the only non-black ending
-    film[3 * pixel] += col.x; film[3 * pixel + 1] += col.y; film[3 * pixel + 2] += col.z;
+    float* dst = stage + 3ull * (uint32_t)task;
+    dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
   }
   if (COMPACT) {
     // compaction by wavefront ballot: rank within the wave from the ballot mask, one atomic
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
       next.px[j] = ray.pos.x; next.py[j] = ray.pos.y; next.pz[j] = ray.pos.z;
       next.dx[j] = ray.dir.x; next.dy[j] = ray.dir.y; next.dz[j] = ray.dir.z;
       next.cr[j] = col.x; next.cg[j] = col.y; next.cb[j] = col.z;
-      next.pixel[j] = pixel;
+      next.pixel[j] = task;
     }
   } else if (active) {
     if (cont) {
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float* __restrict__ fi
 
 // One brute-force pass per big mesh over the rays of the kernel that follows (SOURCE as k_mesh_rays).
 template <int SOURCE>
-static void launch_big_mesh_passes(const FrameParams& fp, PathState cur, const uint32_t* count_in,
+static void launch_big_mesh_passes(const FrameParams& fp, uint32_t n_slots, PathState cur, const uint32_t* count_in,
                                    const BigMeshPass& bmp, hipStream_t stream) {
   for (uint32_t b = 0; b < bmp.n_big; ++b) {
     const BigMesh& m = bmp.big[b];
@@ -651,8 +662,8 @@ static void launch_big_mesh_passes(const FrameParams& fp, PathState cur, const u
     if (tiles_per_seg < 16u) tiles_per_seg = 16u;
     const uint32_t n_segs = (n_tiles + tiles_per_seg - 1) / tiles_per_seg;
     (void)hipMemsetAsync(bmp.q.count, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(grid_for(fp.ntile)), dim3(kBlock), 0, stream,
-                       fp, m.mesh_index, cur, count_in, bmp.q, bmp.keys);
+    hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(grid_for(n_slots)), dim3(kBlock), 0, stream,
+                       fp, m.mesh_index, n_slots, cur, count_in, bmp.q, bmp.keys);
     if (bmp.bvh && bmp.bvh[b].nodes) {
       hipLaunchKernelGGL(k_mesh_bvh, dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
                          bmp.q, bmp.bvh[b].nodes, bmp.bvh[b].faces, fp.sc.tris + m.tri_first, bmp.bvh[b].prm,
@@ -668,27 +679,32 @@ static void launch_big_mesh_passes(const FrameParams& fp, PathState cur, const u
 void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, float* hit_t,
                       float* hit_pos, float* hit_nor, DeviceCounters* counters, const BigMeshPass* bmp,
                       hipStream_t stream) {
-  if (bmp) launch_big_mesh_passes<0>(fp, PathState{}, nullptr, *bmp, stream);
+  if (bmp) launch_big_mesh_passes<0>(fp, fp.ntile, PathState{}, nullptr, *bmp, stream);
   hipLaunchKernelGGL(k_raytrace1, dim3(grid_for(fp.ntile)), dim3(kBlock), 0, stream,
                      fp, ldr, hit_id, hit_t, hit_pos, hit_nor, counters);
 }
 
-void launch_wavefront_iteration(const FrameParams& fp, uint32_t iter, bool compact,
-                                PathState cur, PathState next, uint32_t* queue_count,
-                                float* film, DeviceCounters* counters, const BigMeshPass* bmp, hipStream_t stream) {
-  const dim3 grid(grid_for(fp.ntile)), block(kBlock);
-  hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter, cur, queue_count, film, counters);
+void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
+                            bool compact, PathState cur, PathState next, uint32_t* queue_count,
+                            float* film, float* stage, DeviceCounters* counters, const BigMeshPass* bmp,
+                            hipStream_t stream) {
+  const uint32_t n_slots = fp.ntile * n_iters;
+  const dim3 grid(grid_for(n_slots)), block(kBlock);
+  (void)hipMemsetAsync(stage, 0, sizeof(float) * 3ull * n_slots, stream);
+  hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, cur, queue_count, counters);
   for (int d = 0; d < kPathDepth; ++d) {
-    if (bmp) launch_big_mesh_passes<1>(fp, cur, compact ? queue_count + d : nullptr, *bmp, stream);
+    if (bmp) launch_big_mesh_passes<1>(fp, n_slots, cur, compact ? queue_count + d : nullptr, *bmp, stream);
     if (compact) {
-      hipLaunchKernelGGL(k_bounce<true>, grid, block, 0, stream, fp, iter, d, cur, next,
-                         queue_count + d, queue_count + d + 1, film, counters);
+      hipLaunchKernelGGL(k_bounce<true>, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, next,
+                         queue_count + d, queue_count + d + 1, stage, counters);
       PathState t = cur; cur = next; next = t;
     } else {
-      hipLaunchKernelGGL(k_bounce<false>, grid, block, 0, stream, fp, iter, d, cur, cur,
-                         (const uint32_t*)nullptr, (uint32_t*)nullptr, film, counters);
+      hipLaunchKernelGGL(k_bounce<false>, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, cur,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, stage, counters);
     }
   }
+  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(3u * fp.ntile)), dim3(kBlock), 0, stream,
+                     film + 3ull * fp.pix0, (const float*)stage, fp.ntile, n_iters, iter_first == 1u ? 1 : 0);
 }
 
 void launch_fused(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,

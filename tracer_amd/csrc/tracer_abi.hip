@@ -68,6 +68,7 @@ struct trc_ctx {
 
   // wavefront state (allocated on first use)
   float* state_mem[2] = { nullptr, nullptr };
+  size_t state_slots = 0;              // path slots the state arrays hold (a chunk of iterations x tile pixels)
   PathState state[2];
   uint32_t* queue_count = nullptr;
 
@@ -79,6 +80,7 @@ struct trc_ctx {
   // big meshes: brute-force pass of the launch-per-bounce pipelines (kernels.hip: k_mesh_brute)
   std::vector<BigMesh> big;
   unsigned long long* mesh_keys = nullptr; size_t mesh_keys_cap = 0;
+  size_t mesh_slots = 0;               // ray slots per big mesh the key table and the queue hold
   float* mesh_queue_mem = nullptr;
   MeshRayQueue mesh_queue = {};
   unsigned brute_blocks = 0;
@@ -89,16 +91,18 @@ struct trc_ctx {
 
 namespace {
 
-int ensure_wavefront_state(trc_ctx* c, bool need_second) {
+int ensure_wavefront_state(trc_ctx* c, bool need_second, size_t slots) {
+  if (slots > c->state_slots) { free_dev(c->state_mem[0]); free_dev(c->state_mem[1]); c->state_slots = slots; }
+  const size_t n = c->state_slots;
   for (int b = 0; b < (need_second ? 2 : 1); ++b) {
     if (c->state_mem[b]) continue;
-    HIP_TRY(hipMalloc((void**)&c->state_mem[b], sizeof(float) * 10ull * c->npix));
+    HIP_TRY(hipMalloc((void**)&c->state_mem[b], sizeof(float) * 10ull * n));
     float* p = c->state_mem[b];
     PathState& s = c->state[b];
-    s.px = p; s.py = p + c->npix; s.pz = p + 2ull * c->npix;
-    s.dx = p + 3ull * c->npix; s.dy = p + 4ull * c->npix; s.dz = p + 5ull * c->npix;
-    s.cr = p + 6ull * c->npix; s.cg = p + 7ull * c->npix; s.cb = p + 8ull * c->npix;
-    s.pixel = (int32_t*)(p + 9ull * c->npix);
+    s.px = p; s.py = p + n; s.pz = p + 2ull * n;
+    s.dx = p + 3ull * n; s.dy = p + 4ull * n; s.dz = p + 5ull * n;
+    s.cr = p + 6ull * n; s.cg = p + 7ull * n; s.cb = p + 8ull * n;
+    s.pixel = (int32_t*)(p + 9ull * n);
   }
   if (!c->queue_count) HIP_TRY(hipMalloc((void**)&c->queue_count, sizeof(uint32_t) * (kPathDepth + 1)));
   return TRC_OK;
@@ -138,22 +142,24 @@ int ensure_bvh(trc_ctx* c) {
 
 // Buffers of the big-mesh brute-force passes: key table (one row of npix keys per big mesh) and
 // the ray queue (npix entries: slot + 6 floats, and the counter).
-int ensure_big_mesh_buffers(trc_ctx* c) {
+int ensure_big_mesh_buffers(trc_ctx* c, size_t slots) {
   if (c->big.empty()) return TRC_OK;
-  const size_t need = c->big.size() * (size_t)c->npix;
+  if (slots > c->mesh_slots) { free_dev(c->mesh_queue_mem); c->mesh_slots = slots; }
+  const size_t n = c->mesh_slots;
+  const size_t need = c->big.size() * n;
   if (need > c->mesh_keys_cap) {
     free_dev(c->mesh_keys); c->mesh_keys_cap = 0;
     HIP_TRY(hipMalloc((void**)&c->mesh_keys, sizeof(unsigned long long) * need));
     c->mesh_keys_cap = need;
   }
   if (!c->mesh_queue_mem) {
-    HIP_TRY(hipMalloc((void**)&c->mesh_queue_mem, sizeof(float) * (7ull * c->npix + 64)));
+    HIP_TRY(hipMalloc((void**)&c->mesh_queue_mem, sizeof(float) * (7ull * n + 64)));
     float* p = c->mesh_queue_mem;
     MeshRayQueue& q = c->mesh_queue;
     q.slot = (uint32_t*)p;
-    q.ox = p + c->npix; q.oy = p + 2ull * c->npix; q.oz = p + 3ull * c->npix;
-    q.dx = p + 4ull * c->npix; q.dy = p + 5ull * c->npix; q.dz = p + 6ull * c->npix;
-    q.count = (uint32_t*)(p + 7ull * c->npix);
+    q.ox = p + n; q.oy = p + 2ull * n; q.oz = p + 3ull * n;
+    q.dx = p + 4ull * n; q.dy = p + 5ull * n; q.dz = p + 6ull * n;
+    q.count = (uint32_t*)(p + 7ull * n);
   }
   { int rc = ensure_bvh(c); if (rc) return rc; }
   if (!c->brute_blocks) {
@@ -478,10 +484,10 @@ int trc_raytrace1(trc_ctx* c, const trc_camera* cam) {
   HIP_TRY(hipSetDevice(c->device));
   if (c->record_hits) { int rc = ensure_hit_buffers(c); if (rc) return rc; }
   FrameParams fp = make_params(c, cam, 0);
-  int rc = ensure_big_mesh_buffers(c); if (rc) return rc;
+  int rc = ensure_big_mesh_buffers(c, c->npix); if (rc) return rc;
   BigMeshPass bmp = big_mesh_pass(c);
   const BigMeshPass* pass = c->big.empty() ? nullptr : &bmp;
-  if (pass) { fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = c->npix; }
+  if (pass) { fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = (uint32_t)c->mesh_slots; }
   rc = begin_timing(c); if (rc) return rc;
   if (c->record_hits) launch_raytrace1(fp, c->ldr, c->hit_id, c->hit_t, c->hit_pos, c->hit_nor, c->counters, pass, c->stream);
   else launch_raytrace1(fp, c->ldr, nullptr, nullptr, nullptr, nullptr, c->counters, pass, c->stream);
@@ -506,21 +512,17 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
   const int pipeline = c->pipeline != TRC_PIPE_AUTO ? c->pipeline : (c->big.empty() ? TRC_PIPE_QUEUE : TRC_PIPE_COMPACTED);
   BigMeshPass bmp = {};
   const BigMeshPass* pass = nullptr;
-  if (pipeline == TRC_PIPE_WAVEFRONT || pipeline == TRC_PIPE_COMPACTED) {
-    int rc = ensure_wavefront_state(c, pipeline == TRC_PIPE_COMPACTED); if (rc) return rc;
-    rc = ensure_big_mesh_buffers(c); if (rc) return rc;
-    if (!c->big.empty()) {
-      bmp = big_mesh_pass(c); pass = &bmp;
-      fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = c->npix;
-    }
-  }
+  const bool wave = pipeline == TRC_PIPE_WAVEFRONT || pipeline == TRC_PIPE_COMPACTED;
+  // Iterations per launch sequence (work queue and wavefront pipelines): what fits the staging budget, at
+  // least one; paths per chunk < 2^31; the wavefront pipelines also keep 40-80 B of ray state per path, so
+  // they stop at 2^24 paths per chunk.
   uint32_t chunk_iters = 0;
-  if (pipeline == TRC_PIPE_QUEUE) {
-    // iterations per chunk: what fits the staging budget (at least one), paths per chunk < 2^31
+  if (pipeline == TRC_PIPE_QUEUE || wave) {
     const size_t per_iter = 3ull * fp.ntile;
     size_t fit = ((size_t)c->stage_mb << 20) / (sizeof(float) * per_iter);
     const size_t cap31 = 0x7FFFFFFFull / fp.ntile;
     if (fit > cap31) fit = cap31;
+    if (wave && fit > (size_t(1) << 24) / fp.ntile) fit = (size_t(1) << 24) / fp.ntile;
     if (fit < 1) fit = 1;
     chunk_iters = (uint32_t)(fit < n_iters ? fit : n_iters);
     const size_t need = per_iter * chunk_iters;
@@ -529,6 +531,17 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
       HIP_TRY(hipMalloc((void**)&c->stage, sizeof(float) * need));
       c->stage_floats = need;
     }
+  }
+  if (wave) {
+    const size_t slots = (size_t)fp.ntile * chunk_iters;
+    int rc = ensure_wavefront_state(c, pipeline == TRC_PIPE_COMPACTED, slots); if (rc) return rc;
+    rc = ensure_big_mesh_buffers(c, slots); if (rc) return rc;
+    if (!c->big.empty()) {
+      bmp = big_mesh_pass(c); pass = &bmp;
+      fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = (uint32_t)c->mesh_slots;
+    }
+  }
+  if (pipeline == TRC_PIPE_QUEUE) {
     if (!c->next_task) HIP_TRY(hipMalloc((void**)&c->next_task, sizeof(uint32_t)));
     if (!c->resident_blocks) {
       hipDeviceProp_t prop;
@@ -547,10 +560,12 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
     launch_fused(fp, iter_first, iter_stride, n_iters, c->film, c->counters, c->stream);
   } else {
     const bool compact = pipeline == TRC_PIPE_COMPACTED;
-    for (uint32_t k = 0; k < n_iters; ++k)
-      launch_wavefront_iteration(fp, iter_first + k * iter_stride, compact, c->state[0],
-                                 compact ? c->state[1] : c->state[0], c->queue_count,
-                                 c->film, c->counters, pass, c->stream);
+    for (uint32_t done = 0; done < n_iters; done += chunk_iters) {
+      const uint32_t n = (n_iters - done < chunk_iters) ? n_iters - done : chunk_iters;
+      launch_wavefront_chunk(fp, iter_first + done * iter_stride, iter_stride, n, compact, c->state[0],
+                             compact ? c->state[1] : c->state[0], c->queue_count,
+                             c->film, c->stage, c->counters, pass, c->stream);
+    }
   }
   HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
   launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
