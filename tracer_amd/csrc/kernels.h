@@ -43,13 +43,25 @@ struct PathState {
   int32_t* pixel;                      // owning pixel, or -1 once terminated (idx_d)
 };
 
-struct DeviceCounters {
+// Event counters, banked: a workgroup adds to bank blockIdx.x % kCounterBanks, each bank in a 256-byte
+// block of its own, so the one-atomic-per-wavefront updates of a launch with hundreds of thousands of
+// wavefronts go to 256 different addresses instead of queueing on one (measured: ~12 ns per same-address
+// atomic, i.e. 3 ms per launch of 262 144 wavefronts). The host sums the banks.
+constexpr unsigned kCounterBanks = 256;
+struct alignas(256) CounterBank {
   unsigned long long live_segments;
   unsigned long long paths;
   unsigned long long tri_tests;
   unsigned long long wave_cycles;      // persistent kernels: sum of clock64() spans of their wavefronts
   unsigned long long wave_ref_ticks;   // ... and of wall_clock64() (100 MHz) spans
 };
+struct DeviceCounters { CounterBank bank[kCounterBanks]; };
+
+// Wavefront pipelines (kernels.hip: region_cap): path slots are split into kRegions regions; the live count of
+// region p entering bounce d is queue_count[(d * kRegions + p) * kCountStride] (256 bytes apart).
+constexpr uint32_t kRegions = 256;
+constexpr uint32_t kCountStride = 64;
+constexpr uint32_t kRegionSlack = kRegions * 256;   // slots beyond ntile * n_iters that the region layout may address
 
 // ---- big meshes (scene.h: kBigMeshTris): brute-force pass in front of a closest-hit kernel ------
 struct BigMesh { uint32_t mesh_index, hot_first, tri_first, tri_count; };   // host-side list, in big_slot order
@@ -85,10 +97,11 @@ void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, flo
 // sequence = raygen + kPathDepth bounce launches over ntile * n_iters path slots + k_accumulate.
 // compact = false: state stays at its slot, dead paths flagged (pixel plane = -1).
 // compact = true : survivors are written densely into `next` behind a wave-ballot prefix sum;
-//                  queue_count[d] is the number of live paths entering bounce d.
-// cur / next hold ntile * n_iters entries each, stage 3 * ntile * n_iters floats.
+//                  per region (kRegions of them), one live count per bounce.
+// cur / next hold ntile * n_iters + kRegionSlack entries each, stage 3 * ntile * n_iters floats,
+// queue_count (kPathDepth + 1) * kRegions * kCountStride words.
 void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
-                            bool compact, PathState cur, PathState next, uint32_t* queue_count /*[kPathDepth+1]*/,
+                            bool compact, PathState cur, PathState next, uint32_t* queue_count,
                             float* film, float* stage, DeviceCounters* counters, const BigMeshPass* bmp,
                             hipStream_t stream);
 

@@ -21,6 +21,31 @@ constexpr int kBlock = 256;
 
 static inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
+// Wavefront pipelines: the path slots of a launch sequence are split into kRegions contiguous regions of
+// `cap` slots (a multiple of the workgroup size). A workgroup belongs to one region; survivors of a bounce
+// are compacted WITHIN their region (they can only become fewer), with one live count per region and
+// bounce, each in a 256-byte block of its own -- so the one-atomic-per-wavefront queue reservations of a
+// launch go to 256 addresses instead of one (same measurement as for the counters, kernels.h).
+__host__ __device__ inline uint32_t region_cap(uint32_t n_slots) {
+  const uint32_t per = (n_slots + kRegions - 1) / kRegions;
+  const uint32_t cap = (per + kBlock - 1) / kBlock * kBlock;
+  return cap ? cap : (uint32_t)kBlock;
+}
+__device__ __forceinline__ uint32_t region_initial(uint32_t n_slots, uint32_t cap, uint32_t p) {
+  const uint32_t lo = p * cap;
+  return n_slots > lo ? (n_slots - lo < cap ? n_slots - lo : cap) : 0u;
+}
+// this workgroup's region, its first slot within the region, the region's live count
+struct RegionView { uint32_t p, first, n_in; };
+__device__ __forceinline__ RegionView region_view(uint32_t n_slots, uint32_t cap, const uint32_t* __restrict__ count_in) {
+  const uint32_t bpr = cap / kBlock;
+  RegionView v;
+  v.p = blockIdx.x / bpr;
+  v.first = (blockIdx.x - v.p * bpr) * kBlock;
+  v.n_in = count_in ? count_in[v.p * kCountStride] : region_initial(n_slots, cap, v.p);
+  return v;
+}
+
 // ---- wave64 helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
@@ -106,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* 
   Ray ray = primary_ray(fp, idx);
   uint32_t tt = 0;
   Hit hit = closest_hit(ray, valid, fp.sc, tt, slot);
-  if (counters) count_add(&counters->tri_tests, (unsigned long long)tt);
+  if (counters) count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
   if (!valid) return;
   const f3 lightDir = mk3((float)0.267261, (float)0.801784, (float)0.534522);
   f3 col;
@@ -162,10 +187,18 @@ template <int SOURCE>
 __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t mesh_index, uint32_t n_slots, PathState cur,
                                                      const uint32_t* __restrict__ count_in, MeshRayQueue q,
                                                      unsigned long long* __restrict__ keys) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t n_in = (SOURCE == 1 && count_in) ? *count_in : n_slots;
-  if (blockIdx.x * kBlock >= n_in) return;
-  bool live = i < n_in;
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  bool live;
+  if (SOURCE == 1) {                 // the slots of a wavefront launch sequence, region by region
+    const uint32_t cap = region_cap(n_slots);
+    const RegionView rv = region_view(n_slots, cap, count_in);
+    if (rv.first >= rv.n_in) return;
+    live = rv.first + threadIdx.x < rv.n_in;
+    i = rv.p * cap + rv.first + threadIdx.x;
+  } else {
+    if (blockIdx.x * kBlock >= n_slots) return;
+    live = i < n_slots;
+  }
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
   if (SOURCE == 0) {
     ray = primary_ray(fp, fp.pix0 + i);
@@ -370,13 +403,15 @@ __global__ __launch_bounds__(kBlock) void k_mesh_bvh(MeshRayQueue q, const BvhNo
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                   uint32_t n_slots, PathState st,
                                                   uint32_t* __restrict__ queue_count, DeviceCounters* counters) {
-  const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;      // slot
-  if (idx == 0) {
-    queue_count[0] = n_slots;
+  const uint32_t cap = region_cap(n_slots);
+  const RegionView rv = region_view(n_slots, cap, nullptr);
+  const uint32_t idx = rv.p * cap + rv.first + threadIdx.x;    // slot; initially slot == task
+  if (rv.first == 0 && threadIdx.x == 0) {
+    queue_count[rv.p * kCountStride] = rv.n_in;
 #pragma unroll
-    for (int d = 1; d <= kPathDepth; ++d) queue_count[d] = 0;
+    for (int d = 1; d <= kPathDepth; ++d) queue_count[(d * kRegions + rv.p) * kCountStride] = 0;
   }
-  const bool valid = idx < n_slots;
+  const bool valid = rv.first + threadIdx.x < rv.n_in;
   if (valid) {
     uint32_t s;
     const uint32_t itk = udivmod(idx, fp.div_tile, s);
@@ -386,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
     st.cr[idx] = 1.0f; st.cg[idx] = 1.0f; st.cb[idx] = 1.0f;           // raytrace.cu:99
     st.pixel[idx] = (int32_t)idx;                                     // :101
   }
-  count_add(&counters->paths, valid ? 1ull : 0ull);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, valid ? 1ull : 0ull);
 }
 
 template <bool COMPACT>
@@ -396,10 +431,11 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
                                                   const uint32_t* __restrict__ count_in,
                                                   uint32_t* __restrict__ count_out,
                                                   float* __restrict__ stage, DeviceCounters* counters) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t n_in = COMPACT ? *count_in : n_slots;
-  if (blockIdx.x * kBlock >= n_in) return;                            // whole block past the queue
-  const int32_t task = (i < n_in) ? cur.pixel[i] : -1;
+  const uint32_t cap = region_cap(n_slots);
+  const RegionView rv = region_view(n_slots, cap, COMPACT ? count_in : nullptr);
+  if (rv.first >= rv.n_in) return;                                    // whole block past its region's queue
+  const uint32_t i = rv.p * cap + rv.first + threadIdx.x;
+  const int32_t task = (rv.first + threadIdx.x < rv.n_in) ? cur.pixel[i] : -1;
   const bool active = task >= 0;                                      // raytrace.cu:119-124
   uint32_t s = 0;
   const uint32_t itk = udivmod(active ? (uint32_t)task : 0u, fp.div_tile, s);
@@ -425,11 +461,11 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
     const unsigned lane = lane_id();
     const unsigned total = __popcll(mask);
     unsigned base = 0;
-    if (lane == 0 && total) base = atomicAdd(count_out, total);
+    if (lane == 0 && total) base = atomicAdd(count_out + rv.p * kCountStride, total);
     base = __builtin_amdgcn_readfirstlane(base);
     if (cont) {
       const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
-      const uint32_t j = base + rank;
+      const uint32_t j = rv.p * cap + base + rank;
       next.px[j] = ray.pos.x; next.py[j] = ray.pos.y; next.pz[j] = ray.pos.z;
       next.dx[j] = ray.dir.x; next.dy[j] = ray.dir.y; next.dz[j] = ray.dir.z;
       next.cr[j] = col.x; next.cg[j] = col.y; next.cb[j] = col.z;
@@ -444,8 +480,8 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
       cur.pixel[i] = -1;                                              // raytrace.cu:132,139
     }
   }
-  count_add(&counters->live_segments, active ? 1ull : 0ull);
-  count_add(&counters->tri_tests, (unsigned long long)tt);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, active ? 1ull : 0ull);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
 }
 
 // ---- fused persistent pipeline ------------------------------------------------------------------
@@ -491,12 +527,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
     }
   }
   if (valid) { film[3 * pixel] = acc.x; film[3 * pixel + 1] = acc.y; film[3 * pixel + 2] = acc.z; }
-  count_add(&counters->live_segments, (unsigned long long)live);
-  count_add(&counters->tri_tests, (unsigned long long)tt);
-  count_add(&counters->paths, valid ? (unsigned long long)n_iters : 0ull);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, (unsigned long long)live);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, valid ? (unsigned long long)n_iters : 0ull);
   if (lane_id() == 0) {
-    atomicAdd(&counters->wave_cycles, clock64() - clk0);
-    atomicAdd(&counters->wave_ref_ticks, wall_clock64() - ref0);
+    atomicAdd(&counters->bank[blockIdx.x % kCounterBanks].wave_cycles, clock64() - clk0);
+    atomicAdd(&counters->bank[blockIdx.x % kCounterBanks].wave_ref_ticks, wall_clock64() - ref0);
   }
 }
 
@@ -618,12 +654,12 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
       have = false;
     }
   }
-  count_add(&counters->live_segments, (unsigned long long)live);
-  count_add(&counters->tri_tests, (unsigned long long)tt);
-  count_add(&counters->paths, (unsigned long long)paths);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, (unsigned long long)live);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, (unsigned long long)paths);
   if (lane == 0) {
-    atomicAdd(&counters->wave_cycles, clock64() - clk0);
-    atomicAdd(&counters->wave_ref_ticks, wall_clock64() - ref0);
+    atomicAdd(&counters->bank[blockIdx.x % kCounterBanks].wave_cycles, clock64() - clk0);
+    atomicAdd(&counters->bank[blockIdx.x % kCounterBanks].wave_ref_ticks, wall_clock64() - ref0);
   }
 }
 
@@ -662,7 +698,7 @@ static void launch_big_mesh_passes(const FrameParams& fp, uint32_t n_slots, Path
     if (tiles_per_seg < 16u) tiles_per_seg = 16u;
     const uint32_t n_segs = (n_tiles + tiles_per_seg - 1) / tiles_per_seg;
     (void)hipMemsetAsync(bmp.q.count, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(grid_for(n_slots)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(SOURCE == 1 ? kRegions * (region_cap(n_slots) / kBlock) : grid_for(n_slots)), dim3(kBlock), 0, stream,
                        fp, m.mesh_index, n_slots, cur, count_in, bmp.q, bmp.keys);
     if (bmp.bvh && bmp.bvh[b].nodes) {
       hipLaunchKernelGGL(k_mesh_bvh, dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
@@ -689,14 +725,14 @@ void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t
                             float* film, float* stage, DeviceCounters* counters, const BigMeshPass* bmp,
                             hipStream_t stream) {
   const uint32_t n_slots = fp.ntile * n_iters;
-  const dim3 grid(grid_for(n_slots)), block(kBlock);
+  const dim3 grid(kRegions * (region_cap(n_slots) / kBlock)), block(kBlock);
   (void)hipMemsetAsync(stage, 0, sizeof(float) * 3ull * n_slots, stream);
   hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, cur, queue_count, counters);
   for (int d = 0; d < kPathDepth; ++d) {
-    if (bmp) launch_big_mesh_passes<1>(fp, n_slots, cur, compact ? queue_count + d : nullptr, *bmp, stream);
+    if (bmp) launch_big_mesh_passes<1>(fp, n_slots, cur, compact ? queue_count + d * kRegions * kCountStride : nullptr, *bmp, stream);
     if (compact) {
       hipLaunchKernelGGL(k_bounce<true>, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, next,
-                         queue_count + d, queue_count + d + 1, stage, counters);
+                         queue_count + d * kRegions * kCountStride, queue_count + (d + 1) * kRegions * kCountStride, stage, counters);
       PathState t = cur; cur = next; next = t;
     } else {
       hipLaunchKernelGGL(k_bounce<false>, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, cur,

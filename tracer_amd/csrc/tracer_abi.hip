@@ -104,7 +104,7 @@ int ensure_wavefront_state(trc_ctx* c, bool need_second, size_t slots) {
     s.cr = p + 6ull * n; s.cg = p + 7ull * n; s.cb = p + 8ull * n;
     s.pixel = (int32_t*)(p + 9ull * n);
   }
-  if (!c->queue_count) HIP_TRY(hipMalloc((void**)&c->queue_count, sizeof(uint32_t) * (kPathDepth + 1)));
+  if (!c->queue_count) HIP_TRY(hipMalloc((void**)&c->queue_count, sizeof(uint32_t) * (kPathDepth + 1) * kRegions * kCountStride));
   return TRC_OK;
 }
 
@@ -533,7 +533,7 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
     }
   }
   if (wave) {
-    const size_t slots = (size_t)fp.ntile * chunk_iters;
+    const size_t slots = (size_t)fp.ntile * chunk_iters + kRegionSlack;
     int rc = ensure_wavefront_state(c, pipeline == TRC_PIPE_COMPACTED, slots); if (rc) return rc;
     rc = ensure_big_mesh_buffers(c, slots); if (rc) return rc;
     if (!c->big.empty()) {
@@ -649,11 +649,15 @@ int trc_bind_film(trc_ctx* c, void* dev_ptr) {
 int trc_get_counters(trc_ctx* c, trc_counters* out) {
   if (!c || !out) return fail(TRC_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->device));
-  DeviceCounters h;
+  std::vector<DeviceCounters> hv(1);
+  DeviceCounters& h = hv[0];
   HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  out->live_segments = h.live_segments; out->paths = h.paths; out->tri_tests = h.tri_tests;
-  out->wave_cycles = h.wave_cycles; out->wave_ref_ticks = h.wave_ref_ticks;
+  memset(out, 0, sizeof *out);
+  for (unsigned b = 0; b < kCounterBanks; ++b) {
+    out->live_segments += h.bank[b].live_segments; out->paths += h.bank[b].paths; out->tri_tests += h.bank[b].tri_tests;
+    out->wave_cycles += h.bank[b].wave_cycles; out->wave_ref_ticks += h.bank[b].wave_ref_ticks;
+  }
   return TRC_OK;
 }
 
