@@ -93,6 +93,23 @@ __device__ __forceinline__ f3 normalize_dev(f3 v, bool need) {
   return v * cr_rsqrt(sqr, need);
 }
 
+// Wave-uniform record -> SGPRs. The scene is read-only for the whole launch, but the compiler cannot know
+// that a kernel's stores never alias it and falls back to per-lane vector loads of the same address
+// (global_load_dwordx4 + s_waitcnt vmcnt(0) in front of every object). Reading through the constant
+// address space states the invariance: the copy becomes s_load_dwordx8/x16 and the matrix entries are used
+// as scalar operands of the VALU instructions. `p` must be wave-uniform.
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword records");
+  typedef const __attribute__((address_space(4))) unsigned int* const_dwords;
+  const const_dwords q = (const_dwords)(unsigned long long)p;
+  T out;
+  unsigned int* o = reinterpret_cast<unsigned int*>(&out);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = q[i];
+  return out;
+}
+
 __device__ __forceinline__ Hit no_hit() {   // Ray.inl:30  Hit() : m_t(-1), m_id(-1), vec3s zero
   Hit h; h.t = -1.0f; h.id = -1; h.pos = splat3(0.0f); h.nor = splat3(0.0f); return h;
 }
@@ -323,7 +340,7 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, co
                                        const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[first + k].mi, live);    // Ray.inl:88
+  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, load_uniform(&xf[first + k].mi), live);    // Ray.inl:88
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const float tp = -r[k].pos.y / r[k].dir.y;
@@ -340,7 +357,7 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, c
                                         const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, xf[first + k].mi, live);
+  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, load_uniform(&xf[first + k].mi), live);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const f3 l = -r[k].pos;
@@ -357,7 +374,9 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, c
 
 // Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
 // -x,+x,-y,+y,-z,else +z, taken from the per-object table of world normals.
-__device__ __forceinline__ void cube(Closest& c, const Ray& ray, bool live, const DevXform& xf, const DevCubeExtra& ex) {
+__device__ __forceinline__ void cube(Closest& c, const Ray& ray, bool live, const DevXform& xf_g, const DevCubeExtra& ex_g) {
+  const DevXform xf = load_uniform(&xf_g);
+  const DevCubeExtra ex = load_uniform(&ex_g);
   const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
   const bool hit = slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar, live);
@@ -377,8 +396,10 @@ __device__ __forceinline__ void cube(Closest& c, const Ray& ray, bool live, cons
 // big mesh whose brute-force pass ran before this kernel (kernels.hip: k_mesh_brute), from that pass's
 // (t, face) key of this ray slot: the winning face is then evaluated once more for its normal
 // (same arithmetic, same t).
-__device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, const DevXform& xf,
-                                     const DevMeshExtra& ex, const DevScene& sc, uint32_t slot, uint32_t& tri_tests) {
+__device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, const DevXform& xf_g,
+                                     const DevMeshExtra& ex_g, const DevScene& sc, uint32_t slot, uint32_t& tri_tests) {
+  const DevXform xf = load_uniform(&xf_g);
+  const DevMeshExtra ex = load_uniform(&ex_g);
   const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
   const bool pass = slab(r, ex.bmin, ex.bmax, tNear, tFar, live) && live;
@@ -410,12 +431,12 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, cons
 // Wave-convergent (see the header comment).
 // `slot`: this ray's row in the key table of the big-mesh passes (unused while sc.mesh_keys is null).
 // `gather`: where the per-lane matrix gathers of the held candidates read the DevXform table from -- a copy
-// of sc.xf in LDS when the kernel made one (k_queue), else sc.xf itself.
-__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevScene& sc, uint32_t& tri_tests, uint32_t slot = 0u,
-                                           const DevXform* __restrict__ gather = nullptr) {
+// of sc.xf in LDS when the kernel made one (k_queue), else sc.xf itself. Never null.
+__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevScene& sc, uint32_t& tri_tests, uint32_t slot,
+                                           const DevXform* __restrict__ gather) {
   Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
   const DevXform* __restrict__ xf = sc.xf;
-  const DevXform* __restrict__ xg = gather ? gather : sc.xf;
+  const DevXform* __restrict__ xg = gather;
   uint32_t i = 0;
   Held h; h.any = false; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u;
   TRC_MARK("planes");

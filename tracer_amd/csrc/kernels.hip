@@ -96,8 +96,8 @@ enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE =
 
 __device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uint32_t pixel, uint32_t iter, int depth,
                                            Ray& ray, f3& col, uint32_t& tri_tests, uint32_t slot = 0u,
-                                           const DevXform* __restrict__ gather = nullptr) {
-  Hit hit = closest_hit(ray, live, fp.sc, tri_tests, slot, gather);
+                                           const DevXform* __restrict__ gather = nullptr, bool gather_given = false) {
+  Hit hit = closest_hit(ray, live, fp.sc, tri_tests, slot, gather_given ? gather : fp.sc.xf);
   if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
   const DevMaterial& o = fp.sc.mats[hit.id];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* 
   const bool valid = slot < fp.ntile;        // no early return: closest_hit is wave-convergent
   Ray ray = primary_ray(fp, idx);
   uint32_t tt = 0;
-  Hit hit = closest_hit(ray, valid, fp.sc, tt, slot);
+  Hit hit = closest_hit(ray, valid, fp.sc, tt, slot, fp.sc.xf);
   if (counters) count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
   if (!valid) return;
   const f3 lightDir = mk3((float)0.267261, (float)0.801784, (float)0.534522);
@@ -563,6 +563,7 @@ constexpr uint32_t kGatherMax = TRC_GATHER_MAX;   // DevXform records k_queue ke
 #define TRC_QUEUE_WAVES 5          // resident waves per SIMD the kernel is compiled for
 #endif
 
+template <bool LDS_GATHER>   // the scene's plane + sphere records fit s_xf (the launcher picks the instantiation)
 __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                     uint32_t n_iters, float* __restrict__ stage,
                                                     uint32_t* __restrict__ next_task, DeviceCounters* counters) {
@@ -571,12 +572,10 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
   // The plane / sphere records that held candidates gather per lane (intersect.h: flush_held), copied to LDS once.
   __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];
   const uint32_t n_gather = fp.sc.n_plane + fp.sc.n_sphere;
-  const DevXform* gather = nullptr;
-  if (n_gather <= kGatherMax) {
+  if (LDS_GATHER) {
     const uint32_t n_dw = n_gather * (uint32_t)(sizeof(DevXform) / 4);
     for (uint32_t i = threadIdx.x; i < n_dw; i += kBlock) ((uint32_t*)s_xf)[i] = ((const uint32_t*)fp.sc.xf)[i];
     __syncthreads();
-    gather = s_xf;
   }
   const uint32_t total = fp.ntile * n_iters;
   const unsigned lane = lane_id();
@@ -641,7 +640,8 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
       ring_count -= taken;
     }
     if (__ballot(have) == 0ull) break;
-    const int res = bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, gather);
+    const int res = LDS_GATHER ? bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, s_xf, true)
+                               : bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, fp.sc.xf, true);
     TRC_MARK("bounce_done");
     if (res == STEP_CONTINUE) {
       ++live; ++depth;
@@ -758,7 +758,8 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
   unsigned blocks = (unsigned)((paths + kBlock - 1) / kBlock);
   resident_blocks = resident_blocks / 4u * TRC_QUEUE_WAVES;     // CUs x waves per SIMD (a block = 1 wave per SIMD)
   if (blocks > resident_blocks) blocks = resident_blocks;
-  hipLaunchKernelGGL(k_queue, dim3(blocks), dim3(kBlock), 0, stream,
+  const bool lds_gather = fp.sc.n_plane + fp.sc.n_sphere <= kGatherMax;
+  hipLaunchKernelGGL(lds_gather ? k_queue<true> : k_queue<false>, dim3(blocks), dim3(kBlock), 0, stream,
                      fp, iter_first, iter_stride, n_iters, stage, next_task, counters);
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(3u * fp.ntile)), dim3(kBlock), 0, stream,
                      film + 3ull * fp.pix0, (const float*)stage, fp.ntile, n_iters, iter_first == 1u ? 1 : 0);
