@@ -44,6 +44,20 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
 }
 
 
+// ---- lane predicates as wave masks ------------------------------------------------------------------
+// A predicate that feeds a wave-level decision ("does any lane that matters ...") is kept as the 64-bit
+// mask a v_cmp writes to an SGPR pair: masks combine with scalar-ALU instructions, `mask != 0` is one
+// s_cmp, and lane_of() hands a mask back to v_cndmask / exec as a per-lane bool. __ballot() of a bool
+// that is not itself a comparison costs two VALU instructions (v_cndmask 0/1 + v_cmp_ne) every time.
+// A mask has zeros for the lanes that were inactive where it was computed.
+using lmask = unsigned long long;
+enum { F_OEQ = 1, F_OGT = 2, F_OGE = 3, F_OLT = 4, F_OLE = 5, F_ONE = 6, F_UNE = 14 };            // llvm::CmpInst float predicates
+enum { I_EQ = 32, I_NE = 33, I_UGT = 34, I_UGE = 35, I_ULT = 36, I_ULE = 37 };      // ... integer predicates
+#define TRC_FCMP(a, b, pred) __builtin_amdgcn_fcmpf((a), (b), (pred))
+#define TRC_UCMP(a, b, pred) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), (pred))
+__device__ __forceinline__ lmask exec_mask() { return __builtin_amdgcn_ballot_w64(true); }
+__device__ __forceinline__ bool lane_of(lmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // ---- short correctly-rounded 1/sqrt and reciprocal -------------------------------------------------
 // glm::normalize is v * (1 / sqrt(s)) with BOTH the square root and the division correctly rounded
 // (func_geometric.inl:243, func_exponential.inl:151); hipcc's IEEE sqrtf + division cost 28 VALU
@@ -56,10 +70,10 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
 //          compared with `/` on 2^34 random pairs with 2^-40 <= |a|, |d| < 2^40 (no mismatch)
 // Outside those ranges (zero vectors, denormals, inf, NaN) the wave takes the IEEE path; the
 // choice is made per wavefront with a ballot, so the result is bit-identical either way.
-// `need` = this lane's result is observable (dead / masked lanes must not force the slow path).
-__device__ __forceinline__ float cr_rsqrt(float s, bool need) {
-  const bool ok = (__float_as_uint(s) - 0x0D000000u) < (0x7E800000u - 0x0D000000u);   // 2^-101 <= s < 2^126
-  if (__ballot(need & !ok) == 0ull) {
+// `need` = the lanes whose result is observable (dead / masked lanes must not force the slow path).
+__device__ __forceinline__ float cr_rsqrt(float s, lmask need) {
+  const lmask ok = TRC_UCMP(__float_as_uint(s) - 0x0D000000u, 0x7E800000u - 0x0D000000u, I_ULT);   // 2^-101 <= s < 2^126
+  if ((need & ~ok) == 0ull) {
     const float y = __builtin_amdgcn_rsqf(s);
     const float q0 = s * y;
     const float h = 0.5f * y;
@@ -69,9 +83,9 @@ __device__ __forceinline__ float cr_rsqrt(float s, bool need) {
   }
   return 1.0f / sqrtf(s);
 }
-__device__ __forceinline__ float cr_sqrt(float s, bool need) {
-  const bool ok = (__float_as_uint(s) - 0x0D000000u) < (0x7F800000u - 0x0D000000u);   // 2^-101 <= s < inf
-  if (__ballot(need & !ok) == 0ull) {
+__device__ __forceinline__ float cr_sqrt(float s, lmask need) {
+  const lmask ok = TRC_UCMP(__float_as_uint(s) - 0x0D000000u, 0x7F800000u - 0x0D000000u, I_ULT);   // 2^-101 <= s < inf
+  if ((need & ~ok) == 0ull) {
     const float y = __builtin_amdgcn_rsqf(s);
     const float q0 = s * y;
     const float h = 0.5f * y;
@@ -79,16 +93,16 @@ __device__ __forceinline__ float cr_sqrt(float s, bool need) {
   }
   return sqrtf(s);
 }
-__device__ __forceinline__ float cr_rcp(float x, bool need) {
-  const bool ok = ((__float_as_uint(x) & 0x7FFFFFFFu) - 0x00800000u) < (0x7E800000u - 0x00800000u); // normal, |x| < 2^126
-  if (__ballot(need & !ok) == 0ull) {
+__device__ __forceinline__ float cr_rcp(float x, lmask need) {
+  const lmask ok = TRC_UCMP((__float_as_uint(x) & 0x7FFFFFFFu) - 0x00800000u, 0x7E800000u - 0x00800000u, I_ULT); // normal, |x| < 2^126
+  if ((need & ~ok) == 0ull) {
     const float r0 = __builtin_amdgcn_rcpf(x);
     return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
   }
   return 1.0f / x;
 }
 // glm::normalize (func_geometric.inl:243-244) on the device
-__device__ __forceinline__ f3 normalize_dev(f3 v, bool need) {
+__device__ __forceinline__ f3 normalize_dev(f3 v, lmask need) {
   const float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
   return v * cr_rsqrt(sqr, need);
 }
@@ -115,7 +129,7 @@ __device__ __forceinline__ Hit no_hit() {   // Ray.inl:30  Hit() : m_t(-1), m_id
 }
 
 // Ray.inl:50-57: two point transforms, direction RE-normalised in object space
-__device__ __forceinline__ Ray to_object_space(const Ray& ray, const Affine& mi, bool live) {
+__device__ __forceinline__ Ray to_object_space(const Ray& ray, const Affine& mi, lmask live) {
   f3 pos = xform_point(mi, ray.pos);
   f3 point = xform_point(mi, ray.pos + ray.dir);
   Ray r; r.pos = pos; r.dir = normalize_dev(point - pos, live);
@@ -124,11 +138,11 @@ __device__ __forceinline__ Ray to_object_space(const Ray& ray, const Affine& mi,
 
 // Ray.inl:189-226 Moeller-Trumbore with barycentric normal interpolation and back-face cull.
 // Returns t (or -1 for "no hit", the m_t of a default Hit) and the un-normalised normal.
-__device__ __forceinline__ float hit_triangle(const Ray& ray, const DevTri& tri, f3& nor, bool need = true) {
+__device__ __forceinline__ float hit_triangle(const Ray& ray, const DevTri& tri, f3& nor, lmask need = exec_mask()) {
   f3 pvec = cross(ray.dir, tri.e2);
   float det = dot(tri.e1, pvec);
   if (gabs(det) < kEps) return -1.0f;
-  det = cr_rcp(det, need);
+  det = cr_rcp(det, need & exec_mask());
   f3 tvec = ray.pos - tri.v0;
   float bx = dot(tvec, pvec) * det;
   if (bx < 0.0f || bx > 1.0f) return -1.0f;
@@ -154,7 +168,8 @@ __device__ __forceinline__ float div_core(float a, float d, float r) {
   q = __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
   return __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
 }
-__device__ __forceinline__ bool slab(const Ray& ray, f3 bmin, f3 bmax, float& tNear, float& tFar, bool need) {
+// Returns the lanes (of `need`) for which Ray.inl:127 / :167 does NOT return "no hit".
+__device__ __forceinline__ lmask slab(const Ray& ray, f3 bmin, f3 bmax, float& tNear, float& tFar, lmask need) {
   const f3 a0 = bmin - ray.pos, a1 = bmax - ray.pos;
   const f3 d = ray.dir;
   f3 tMin, tMax;
@@ -163,8 +178,8 @@ __device__ __forceinline__ bool slab(const Ray& ray, f3 bmin, f3 bmax, float& tN
                                    min3f(__builtin_fabsf(d.x), __builtin_fabsf(d.y), __builtin_fabsf(d.z)));
   const float hi = __builtin_fmaxf(max3f(__builtin_fabsf(a0.x), __builtin_fabsf(a0.y), __builtin_fabsf(a0.z)),
                                    max3f(__builtin_fabsf(a1.x), __builtin_fabsf(a1.y), __builtin_fabsf(a1.z)));
-  const bool ok = (lo >= 0x1p-40f) & (hi < 0x1p40f);
-  if (__ballot(need & !ok) == 0ull) {
+  const lmask ok = TRC_FCMP(lo, 0x1p-40f, F_OGE) & TRC_FCMP(hi, 0x1p40f, F_OLT);
+  if ((need & ~ok) == 0ull) {
     const float rx0 = __builtin_amdgcn_rcpf(d.x), ry0 = __builtin_amdgcn_rcpf(d.y), rz0 = __builtin_amdgcn_rcpf(d.z);
     const float rx = __builtin_fmaf(__builtin_fmaf(-d.x, rx0, 1.0f), rx0, rx0);
     const float ry = __builtin_fmaf(__builtin_fmaf(-d.y, ry0, 1.0f), ry0, ry0);
@@ -179,26 +194,26 @@ __device__ __forceinline__ bool slab(const Ray& ray, f3 bmin, f3 bmax, float& tN
   f3 t2 = gmax(tMin, tMax);
   tNear = gmax(gmax(t1.x, t1.y), t1.z);
   tFar = gmin(gmin(t2.x, t2.y), t2.z);
-  return !(tNear > tFar || tFar < 0.0f);
+  return need & ~(TRC_FCMP(tNear, tFar, F_OGT) | TRC_FCMP(tFar, 0.0f, F_OLT));     // !(tNear > tFar || tFar < 0)
 }
 
 // Branch-free Moeller-Trumbore for the cooperative test: same arithmetic as hit_triangle(), every
 // rejection folded into one predicate (the rejected lanes' values are never observed).
-__device__ __forceinline__ bool hit_triangle_all(const Ray& ray, const DevTri& tri, bool valid, float& t, f3& nor) {
+__device__ __forceinline__ lmask hit_triangle_all(const Ray& ray, const DevTri& tri, lmask valid, float& t, f3& nor) {
   const f3 pvec = cross(ray.dir, tri.e2);
   const float det = dot(tri.e1, pvec);
-  bool ok = valid & !(gabs(det) < kEps);
+  lmask ok = valid & ~TRC_FCMP(__builtin_fabsf(det), kEps, F_OLT);
   const float inv = cr_rcp(det, ok);
   const f3 tvec = ray.pos - tri.v0;
   const float bx = dot(tvec, pvec) * inv;
-  ok &= !((bx < 0.0f) | (bx > 1.0f));
+  ok &= ~(TRC_FCMP(bx, 0.0f, F_OLT) | TRC_FCMP(bx, 1.0f, F_OGT));
   const f3 qvec = cross(tvec, tri.e1);
   const float by = dot(ray.dir, qvec) * inv;
-  ok &= !((by < 0.0f) | ((bx + by) > 1.0f));
+  ok &= ~(TRC_FCMP(by, 0.0f, F_OLT) | TRC_FCMP(bx + by, 1.0f, F_OGT));
   t = dot(tri.e2, qvec) * inv;
   const float bz = 1.0f - bx - by;
   nor = tri.n0 * bz + tri.n1 * bx + tri.n2 * by;
-  ok &= !(dot(ray.dir, nor) > 0);
+  ok &= ~TRC_FCMP(dot(ray.dir, nor), 0.0f, F_OGT);
   return ok;
 }
 
@@ -221,14 +236,14 @@ constexpr int kMaxWavesPerBlock = 4;
 // pass (the 20-triangle icosahedron: 3 rays on 60 lanes), larger meshes one ray per 64-triangle
 // chunk. Every hit does one ds_min_u64 on its ray's key; the winner then leaves its normal in the
 // slot and the ray's own lane collects (t, normal) at the end.
-__device__ __forceinline__ float mesh_closest(const Ray& r, bool pass, const DevTri* __restrict__ tris,
+__device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const DevTri* __restrict__ tris,
                                               const DevMeshExtra& ex, f3& bn, uint32_t& tri_tests) {
   __shared__ MeshSlot s_slots[kMaxWavesPerBlock * 64];
   const uint32_t first = ex.tri_first, count = ex.tri_count;
   float best = FLT_MAX;
   bn = splat3(0.0f);
-  const unsigned long long mask = __ballot(pass);
   if (mask == 0ull || count == 0u) return best;
+  const bool pass = lane_of(mask);
   const unsigned n_pass = __popcll(mask);
   if (pass) tri_tests += count;
   const unsigned lane = lane_id();
@@ -248,22 +263,22 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, bool pass, const Dev
     }
     const unsigned sub = (lane * ex.group_magic) >> 16;         // lane / G
     const unsigned tl = lane - sub * G;                         // lane % G
-    const bool lane_used = sub < R;
+    const lmask lane_used = TRC_UCMP(sub, R, I_ULT);
     for (uint32_t base = 0; base < count; base += 64u) {
       const uint32_t ti = base + tl;
-      const bool tvalid = lane_used & (ti < count);
-      const DevTri tri = tris[first + (tvalid ? ti : 0u)];
+      const lmask tvalid = lane_used & TRC_UCMP(ti, count, I_ULT);
+      const DevTri tri = tris[first + (lane_of(tvalid) ? ti : 0u)];
       for (unsigned s0 = 0; s0 < n_pass; s0 += R) {
         TRC_MARK("mesh_pass");
         const unsigned slot = s0 + sub;
-        const bool valid = tvalid & (slot < n_pass);
-        MeshSlot& m = slots[valid ? slot : 0u];
+        const lmask valid = tvalid & TRC_UCMP(slot, n_pass, I_ULT);
+        MeshSlot& m = slots[lane_of(valid) ? slot : 0u];
         Ray rr;
         rr.pos = mk3(m.px, m.py, m.pz); rr.dir = mk3(m.dx, m.dy, m.dz);
         float t; f3 n;
-        const bool hit = hit_triangle_all(rr, tri, valid, t, n);
+        const lmask hit = hit_triangle_all(rr, tri, valid, t, n);
         // Ray.inl:174  thit.m_t > 0 && thit.m_t < hit.m_t (initially FLT_MAX); positive floats order as their bits
-        const bool cand = hit & (t > 0.0f) & (t < FLT_MAX);
+        const bool cand = lane_of(hit & TRC_FCMP(t, 0.0f, F_OGT) & TRC_FCMP(t, FLT_MAX, F_OLT));
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | ti;
         if (cand) atomicMin(&m.key, key);
         if (cand && m.key == key) { m.nx = n.x; m.ny = n.y; m.nz = n.z; }
@@ -312,31 +327,32 @@ __device__ __forceinline__ void consider(Closest& c, const Ray& ray, float t, ui
 // group with the held object's matrix gathered per lane. If any lane meets a second candidate
 // while holding one, the wave flushes first -- every candidate still goes through consider() in
 // object order, so the result is the one the plain loop produces.
-struct Held { bool any; float t; f3 p; uint32_t k; };
+struct Held { lmask any; float t; f3 p; uint32_t k; };   // any: the lanes holding a candidate (wave mask)
 
 template <bool SPHERE>
 __device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h) {
-  if (__ballot(h.any) == 0ull) return;
-  if (h.any) {
+  if (h.any == 0ull) return;
+  if (lane_of(h.any)) {
     const DevXform& x = xg[h.k];                                // per-lane gather (a handful of distinct records)
     const Affine m = x.m;
     f3 wn = x.nor_y;                                            // planes: object +y (Ray.inl:156, :62)
-    if (SPHERE) wn = normalize_dev(xform_dir(m, normalize_dev(h.p, true)), true);   // Ray.inl:116, :62
+    if (SPHERE) wn = normalize_dev(xform_dir(m, normalize_dev(h.p, h.any)), h.any);   // Ray.inl:116, :62
     consider(c, ray, h.t, x.id, m, h.p, wn);
   }
-  h.any = false;
+  h.any = 0ull;
 }
 template <bool SPHERE>
 __device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h,
-                                     bool cand, float t, f3 p, uint32_t k) {
-  if (__ballot(cand & h.any) != 0ull) flush_held<SPHERE>(c, ray, xg, h);
-  if (cand) { h.any = true; h.t = t; h.p = p; h.k = k; }
+                                     lmask cand, float t, f3 p, uint32_t k) {
+  if ((cand & h.any) != 0ull) flush_held<SPHERE>(c, ray, xg, h);
+  if (lane_of(cand)) { h.t = t; h.p = p; h.k = k; }
+  h.any |= cand;
 }
 
 // K planes at once. Ray.inl:142-158: t = -o.y/d.y, hit iff |x|,|z| < 0.5 (strict); the normal is
 // always object +y -> DevXform::nor_y. Only t > 0 competes (Ray.inl:72).
 template <int K>
-__device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf,
+__device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
                                        const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
@@ -345,15 +361,15 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, bool live, co
   for (int k = 0; k < K; ++k) {
     const float tp = -r[k].pos.y / r[k].dir.y;
     const f3 p = r[k].pos + tp * r[k].dir;
-    const bool in = (p.x < 0.5f) & (p.z < 0.5f) & (p.x > -0.5f) & (p.z > -0.5f);
-    hold<false>(c, ray, xg, h, live & in & (tp > 0.0f), tp, p, first + k);
+    const lmask in = TRC_FCMP(p.x, 0.5f, F_OLT) & TRC_FCMP(p.z, 0.5f, F_OLT) & TRC_FCMP(p.x, -0.5f, F_OGT) & TRC_FCMP(p.z, -0.5f, F_OGT);
+    hold<false>(c, ray, xg, h, live & in & TRC_FCMP(tp, 0.0f, F_OGT), tp, p, first + k);
   }
 }
 
 // K spheres at once. Ray.inl:103-118: radius 0.5, geometric method, normal = normalize(pos),
 // then Ray.inl:62 normalize(M * (n, 0)) -- both only for a held candidate (flush_held).
 template <int K>
-__device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, const DevXform* __restrict__ xf,
+__device__ __forceinline__ void spheres(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
                                         const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
@@ -364,22 +380,23 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, bool live, c
     const float s = dot(l, r[k].dir);
     const float l2 = dot(l, l);
     const float m2 = l2 - s * s;
-    const bool hit = live & !((s < 0.0f) & (l2 > 0.25f)) & !(m2 > 0.25f);
+    const lmask outside = TRC_FCMP(l2, 0.25f, F_OGT);
+    const lmask hit = live & ~(TRC_FCMP(s, 0.0f, F_OLT) & outside) & ~TRC_FCMP(m2, 0.25f, F_OGT);
     const float q = cr_sqrt(0.25f - m2, hit);
-    const float th = (l2 > 0.25f) ? s - q : s + q;
+    const float th = lane_of(outside) ? s - q : s + q;
     const f3 p = r[k].pos + r[k].dir * th;
-    hold<true>(c, ray, xg, h, hit & (th > 0.0f), th, p, first + k);
+    hold<true>(c, ray, xg, h, hit & TRC_FCMP(th, 0.0f, F_OGT), th, p, first + k);
   }
 }
 
 // Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
 // -x,+x,-y,+y,-z,else +z, taken from the per-object table of world normals.
-__device__ __forceinline__ void cube(Closest& c, const Ray& ray, bool live, const DevXform& xf_g, const DevCubeExtra& ex_g) {
+__device__ __forceinline__ void cube(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g, const DevCubeExtra& ex_g) {
   const DevXform xf = load_uniform(&xf_g);
   const DevCubeExtra ex = load_uniform(&ex_g);
   const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
-  const bool hit = slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar, live);
+  const bool hit = lane_of(slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar, live));
   const float th = tNear > 0.0f ? tNear : tFar;
   const f3 p = r.pos + r.dir * th;
   // six wave-uniform candidates: select from the last test to the first
@@ -396,13 +413,14 @@ __device__ __forceinline__ void cube(Closest& c, const Ray& ray, bool live, cons
 // big mesh whose brute-force pass ran before this kernel (kernels.hip: k_mesh_brute), from that pass's
 // (t, face) key of this ray slot: the winning face is then evaluated once more for its normal
 // (same arithmetic, same t).
-__device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, const DevXform& xf_g,
+__device__ __forceinline__ void mesh(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g,
                                      const DevMeshExtra& ex_g, const DevScene& sc, uint32_t slot, uint32_t& tri_tests) {
   const DevXform xf = load_uniform(&xf_g);
   const DevMeshExtra ex = load_uniform(&ex_g);
   const Ray r = to_object_space(ray, xf.mi, live);
   float tNear, tFar;
-  const bool pass = slab(r, ex.bmin, ex.bmax, tNear, tFar, live) && live;
+  const lmask pass_m = slab(r, ex.bmin, ex.bmax, tNear, tFar, live);
+  const bool pass = lane_of(pass_m);
   f3 bn;
   float tb;
   if (sc.mesh_keys != nullptr && ex.big_slot != kNotBig) {
@@ -417,14 +435,15 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, cons
       }
     }
   } else {
-    tb = mesh_closest(r, pass, sc.tris, ex, bn, tri_tests);
+    tb = mesh_closest(r, pass_m, sc.tris, ex, bn, tri_tests);
   }
   // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero normal
   // forward; the world-space distance test then rejects it because |o + d*FLT_MAX|^2 overflows
   // to inf for any normalised d -> explicit miss here.
-  const bool hit = pass && tb != FLT_MAX;
+  const lmask hit_m = pass_m & TRC_FCMP(tb, FLT_MAX, F_UNE);
+  const bool hit = lane_of(hit_m);
   const f3 p = r.pos + r.dir * tb;
-  const f3 wn = normalize_dev(xform_dir(xf.m, bn), hit);      // Ray.inl:62
+  const f3 wn = normalize_dev(xform_dir(xf.m, bn), hit_m);    // Ray.inl:62
   consider(c, ray, hit ? tb : -1.0f, xf.id, xf.m, p, wn);
 }
 
@@ -432,13 +451,14 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, bool live, cons
 // `slot`: this ray's row in the key table of the big-mesh passes (unused while sc.mesh_keys is null).
 // `gather`: where the per-lane matrix gathers of the held candidates read the DevXform table from -- a copy
 // of sc.xf in LDS when the kernel made one (k_queue), else sc.xf itself. Never null.
-__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live, const DevScene& sc, uint32_t& tri_tests, uint32_t slot,
+__device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const DevScene& sc, uint32_t& tri_tests, uint32_t slot,
                                            const DevXform* __restrict__ gather) {
+  const lmask live = __ballot(live_lane);
   Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
   const DevXform* __restrict__ xf = sc.xf;
   const DevXform* __restrict__ xg = gather;
   uint32_t i = 0;
-  Held h; h.any = false; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u;
+  Held h; h.any = 0ull; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u;
   TRC_MARK("planes");
   for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, live, xf, xg, i, h);
   if (i < sc.n_plane) planes<1>(c, ray, live, xf, xg, i, h);

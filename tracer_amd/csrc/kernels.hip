@@ -71,7 +71,7 @@ __device__ __forceinline__ Ray primary_ray(const FrameParams& fp, uint32_t idx) 
 
 // initBuffersKernel, raytrace.cu:72-96: +-1 pixel jitter and thin-lens depth of field, all
 // from the one triple rand[idx] (x, y reused by jitter and lens).
-__device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx, uint32_t iter, bool need = true) {
+__device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx, uint32_t iter, lmask need = exec_mask()) {
   uint32_t x;
   const uint32_t y = udivmod(idx, fp.div_w, x);
   f3 r = rand3(fp.seed_lo, fp.seed_hi, idx, iter, 0u);
@@ -208,9 +208,10 @@ __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t m
   }
   const DevXform& xf = fp.sc.xf[fp.sc.n_plane + fp.sc.n_sphere + fp.sc.n_cube + mesh_index];
   const DevMeshExtra& ex = fp.sc.meshes[mesh_index];
-  const Ray r = to_object_space(ray, xf.mi, live);                       // exactly as mesh() in intersect.h
+  const lmask live_m = __ballot(live);
+  const Ray r = to_object_space(ray, xf.mi, live_m);                     // exactly as mesh() in intersect.h
   float tNear, tFar;
-  const bool pass = slab(r, ex.bmin, ex.bmax, tNear, tFar, live) && live;
+  const bool pass = lane_of(slab(r, ex.bmin, ex.bmax, tNear, tFar, live_m));
   // a ray with a NaN coordinate passes the slab test (Ray.inl:167 is written with `>` and `<`) and then
   // fails every triangle, because each t it produces is NaN; it gets the "no hit" key without being queued.
   const bool finite = (r.pos.x == r.pos.x) & (r.pos.y == r.pos.y) & (r.pos.z == r.pos.z) &
@@ -244,7 +245,6 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
   const uint32_t nq = *q.count;
   const uint32_t n_rb = (nq + kBruteRays - 1) / kBruteRays;
   const uint32_t n_items = n_rb * n_segs;
-  const unsigned lane = lane_id();
   for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
     const uint32_t seg = item / n_rb;
     const uint32_t rb = item - seg * n_rb;
@@ -322,10 +322,9 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
 #pragma unroll
         for (int r = 0; r < kRaysPerLane; ++r) {
           if (open_mask[r] == 0ull) continue;
-          const bool open_lane = (open_mask[r] >> lane) & 1ull;
           float t; f3 n;
-          const bool hit = hit_triangle_all(Ray{o[r], d[r]}, tri, valid[r] & open_lane, t, n);
-          if (hit & (t > 0.0f) & (t < FLT_MAX)) {          // Ray.inl:174
+          const lmask hit = hit_triangle_all(Ray{o[r], d[r]}, tri, open_mask[r] & __ballot(valid[r]), t, n);
+          if (lane_of(hit & TRC_FCMP(t, 0.0f, F_OGT) & TRC_FCMP(t, FLT_MAX, F_OLT))) {          // Ray.inl:174
             const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | ti;
             best[r] = key < best[r] ? key : best[r];
           }
@@ -614,7 +613,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
         uint32_t g_pixel;
         const uint32_t g_itk = udivmod(gen ? pool_next + lane : 0u, fp.div_tile, g_pixel);
         g_pixel += fp.pix0;
-        const Ray g = camera_sample(fp, g_pixel, iter_first + g_itk * iter_stride, gen);
+        const Ray g = camera_sample(fp, g_pixel, iter_first + g_itk * iter_stride, TRC_UCMP(lane, take, I_ULT));
         if (gen) {
           RaySlot& o = ring[(ring_head + ring_count + lane) & (kRing - 1u)];
           o.px = g.pos.x; o.py = g.pos.y; o.pz = g.pos.z; o.dx = g.dir.x; o.dy = g.dir.y; o.dz = g.dir.z;
