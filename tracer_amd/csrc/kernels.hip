@@ -115,7 +115,7 @@ __device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uin
   } else {
     rnd = rand3(fp.seed_lo, fp.seed_hi, pixel, iter, 1u + (uint32_t)depth);
   }
-  ray.dir = bounce(o.mat_type, o.ior, ray.dir, hit.nor, rnd);              // :156-157
+  ray.dir = bounce(o.mat_type, o.ior, o.inv_ior, ray.dir, hit.nor, rnd);              // :156-157
   ray.pos = hit.pos + kEps * ray.dir;                                      // :159
   return STEP_CONTINUE;
 }

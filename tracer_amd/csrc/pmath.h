@@ -13,9 +13,22 @@
 #include <cmath>
 #include <cstring>
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "crmath.h"
+#endif
+
 #pragma clang fp contract(off)
 
 namespace trc {
+
+// sqrtf: the short correctly-rounded sequence of crmath.h on the device, libm elsewhere (same values).
+TRC_HD float pm_sqrtf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return sqrt_active(x);
+#else
+  return sqrtf(x);
+#endif
+}
 
 // ---- division by a wave-uniform divisor --------------------------------------------------------
 // a / d, correctly rounded, from rd = RN(1/d) (computed once on the host): the quotient estimate and
@@ -81,16 +94,18 @@ TRC_HD float pm_asin_poly(float x) { // |x| <= 0.5
   return fmaf(x * z, p, x);
 }
 
+// acos(x) = 2 asin(sqrt((1 - x) / 2)) for x > 1/2, pi - 2 asin(sqrt((1 + x) / 2)) for x < -1/2, pi/2 - asin(x)
+// between. Both tails take the root of fmaf(-0.5, |x|, 0.5) -- for x < -1/2 that is the fmaf(0.5, x, 0.5) of
+// the defining formula, the same product and sum -- so one square root and one polynomial serve all three
+// cases (lanes of a wavefront fall into all of them); pm_sqrtf is sqrtf, correctly rounded either way.
 TRC_HD float pm_acosf(float x) {
-  if (x > 0.5f) {
-    float s = sqrtf(fmaf(-0.5f, x, 0.5f));
-    return 2.0f * pm_asin_poly(s);
-  } else if (x < -0.5f) {
-    float s = sqrtf(fmaf(0.5f, x, 0.5f));
-    return fmaf(-2.0f, pm_asin_poly(s), 3.14159274101257324f);
-  } else {
-    return 1.57079637050628662f - pm_asin_poly(x);
-  }
+  const float ax = x < 0.0f ? -x : x;
+  const bool tail = ax > 0.5f;
+  const float s = pm_sqrtf(fmaf(-0.5f, ax, 0.5f));
+  const float p = pm_asin_poly(tail ? s : x);
+  if (x > 0.5f) return 2.0f * p;
+  if (x < -0.5f) return fmaf(-2.0f, p, 3.14159274101257324f);
+  return 1.57079637050628662f - p;
 }
 
 TRC_HD double pm_bits2d(uint64_t b) {

@@ -86,7 +86,7 @@ struct alignas(16) DevMeshExtra {
 constexpr uint32_t kNotBig = 0xFFFFFFFFu;
 constexpr uint32_t kBigMeshTris = 1024;     // from here on a mesh gets its own brute-force pass
 constexpr uint32_t kMeshTile = 256;         // triangles per LDS tile of that pass
-struct alignas(16) DevMaterial  { f3 color; float emit; float brdf; float ior; int32_t mat_type; int32_t pad; };
+struct alignas(16) DevMaterial  { f3 color; float emit; float brdf; float ior; int32_t mat_type; float inv_ior; };   // inv_ior = 1.0f / ior
 static_assert(sizeof(DevCubeExtra) == 80 && sizeof(DevMeshExtra) == 48 && sizeof(DevMaterial) == 32, "extras");
 
 struct DevTri;

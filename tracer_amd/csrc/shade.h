@@ -37,30 +37,40 @@ TRC_HD f3 rand_vector_hem(float rand1, float rand2, f3 nor) {
 }
 
 // Material.inl:58-67: exact unpolarised Fresnel; 1 on total internal reflection
-TRC_HD float reflectance(f3 inc, f3 nor, float n1, float n2) {
-  float n = n1 / n2;
+// `n` = n1 / n2, formed by the caller (it is 1/ior or ior: one of two per-object constants).
+TRC_HD float reflectance(f3 inc, f3 nor, float n1, float n2, float n) {
   float cosI = -dot(nor, inc);
   float sinT2 = n * n * (1.0f - cosI * cosI);
   if (sinT2 > 1.0f) return 1.0f;
-  float cosT = sqrtf(1.0f - sinT2);
+  float cosT = pm_sqrtf(1.0f - sinT2);
   float rOrth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
   float rPar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
   return (rOrth * rOrth + rPar * rPar) / 2.0f;
 }
 
 // Material.inl:69-106
-TRC_HD f3 bounce(int mat_type, float ior, f3 rd, f3 nor, f3 randvec) {
+// core/func_geometric.inl:311-317 (vecmath.h: refract) with the device's short square root
+TRC_HD f3 refract_pm(f3 I, f3 N, float eta) {
+  float dotValue = dot(N, I);
+  float k = 1.0f - eta * eta * (1.0f - dotValue * dotValue);
+  if (k < 0.0f) return splat3(0.0f);
+  return eta * I - (eta * dotValue + pm_sqrtf(k)) * N;
+}
+
+// `inv_ior` = 1.0f / ior, divided once per object at upload: n1 / n2 of Material.inl:100, :104 is 1/ior from
+// outside and ior / 1 = ior from inside.
+TRC_HD f3 bounce(int mat_type, float ior, float inv_ior, f3 rd, f3 nor, f3 randvec) {
   if (mat_type == REF_DIFF) {
     return rand_vector_hem(randvec.x, randvec.y, nor);
   } else if (mat_type == REF_MIRR) {
     return reflect(rd, nor);
   } else {
-    float n1, n2; f3 nnor;
-    if (dot(rd, nor) < 0.0f) { n1 = 1.0f; n2 = ior; nnor = nor; }     // from outside
-    else                     { n1 = ior; n2 = 1.0f; nnor = -nor; }    // from inside
-    float refl = reflectance(rd, nnor, n1, n2);
+    float n1, n2, eta; f3 nnor;
+    if (dot(rd, nor) < 0.0f) { n1 = 1.0f; n2 = ior; eta = inv_ior; nnor = nor; }     // from outside
+    else                     { n1 = ior; n2 = 1.0f; eta = ior; nnor = -nor; }        // from inside
+    float refl = reflectance(rd, nnor, n1, n2, eta);
     if (randvec.x < refl) return reflect(rd, nnor);
-    return refract(rd, nnor, n1 / n2);
+    return refract_pm(rd, nnor, eta);
   }
 }
 

@@ -302,6 +302,7 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
   for (size_t i = 0; i < objs.size(); ++i) {
     DevMaterial& m = mats[i]; memset(&m, 0, sizeof m);
     m.color = objs[i].color; m.emit = objs[i].emit; m.brdf = objs[i].brdf; m.ior = objs[i].ior; m.mat_type = objs[i].mat_type;
+    m.inv_ior = 1.0f / objs[i].ior;
   }
   auto append = [&](const void* p, size_t n) {
     size_t off = blob.size();
