@@ -130,14 +130,20 @@ __device__ __forceinline__ lmask slab(const Ray& ray, f3 bmin, f3 bmax, float& t
     const float rz = __builtin_fmaf(__builtin_fmaf(-d.z, rz0, 1.0f), rz0, rz0);
     tMin = mk3(div_core(a0.x, d.x, rx), div_core(a0.y, d.y, ry), div_core(a0.z, d.z, rz));
     tMax = mk3(div_core(a1.x, d.x, rx), div_core(a1.y, d.y, ry), div_core(a1.z, d.z, rz));
+    // glm::min / glm::max are compare-and-select (func_common.inl:296, :314); here they may be v_min / v_max:
+    // every quotient of a needed lane is finite and nonzero (|a|, |d| in range), so no signed-zero or NaN case
+    // can tell the two apart. (A ray with a NaN coordinate has an all-NaN direction in every object space --
+    // the normalisation spreads it -- so all six of its quotients are NaN and so are both results, either way.)
+    tNear = max3f(__builtin_fminf(tMin.x, tMax.x), __builtin_fminf(tMin.y, tMax.y), __builtin_fminf(tMin.z, tMax.z));
+    tFar = min3f(__builtin_fmaxf(tMin.x, tMax.x), __builtin_fmaxf(tMin.y, tMax.y), __builtin_fmaxf(tMin.z, tMax.z));
   } else {
     tMin = a0 / d;
     tMax = a1 / d;
+    f3 t1 = gmin(tMin, tMax);
+    f3 t2 = gmax(tMin, tMax);
+    tNear = gmax(gmax(t1.x, t1.y), t1.z);
+    tFar = gmin(gmin(t2.x, t2.y), t2.z);
   }
-  f3 t1 = gmin(tMin, tMax);
-  f3 t2 = gmax(tMin, tMax);
-  tNear = gmax(gmax(t1.x, t1.y), t1.z);
-  tFar = gmin(gmin(t2.x, t2.y), t2.z);
   return need & ~(TRC_FCMP(tNear, tFar, F_OGT) | TRC_FCMP(tFar, 0.0f, F_OLT));     // !(tNear > tFar || tFar < 0)
 }
 
