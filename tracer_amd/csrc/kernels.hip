@@ -18,6 +18,10 @@
 namespace trc {
 
 constexpr int kBlock = 256;
+#ifndef TRC_GATHER_MAX
+#define TRC_GATHER_MAX 16
+#endif
+constexpr uint32_t kGatherMax = TRC_GATHER_MAX;   // DevXform records k_queue / k_bounce keep in LDS (2 KB)
 
 static inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
   count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, valid ? 1ull : 0ull);
 }
 
-template <bool COMPACT>
+template <bool COMPACT, bool LDS_GATHER>
 __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                   uint32_t n_slots, int depth,
                                                   PathState cur, PathState next,
@@ -433,6 +437,12 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
   const uint32_t cap = region_cap(n_slots);
   const RegionView rv = region_view(n_slots, cap, COMPACT ? count_in : nullptr);
   if (rv.first >= rv.n_in) return;                                    // whole block past its region's queue
+  __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];              // as in k_queue: table of the held candidates' gathers
+  if (LDS_GATHER) {
+    const uint32_t n_dw = (fp.sc.n_plane + fp.sc.n_sphere) * (uint32_t)(sizeof(DevXform) / 4);
+    for (uint32_t k = threadIdx.x; k < n_dw; k += kBlock) ((uint32_t*)s_xf)[k] = ((const uint32_t*)fp.sc.xf)[k];
+    __syncthreads();
+  }
   const uint32_t i = rv.p * cap + rv.first + threadIdx.x;
   const int32_t task = (rv.first + threadIdx.x < rv.n_in) ? cur.pixel[i] : -1;
   const bool active = task >= 0;                                      // raytrace.cu:119-124
@@ -447,7 +457,8 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
     ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
     col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
   }
-  const int res = bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i);
+  const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true)
+                             : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i);
   const bool cont = (res == STEP_CONTINUE);
   if (res == STEP_LIGHT) {                                            // the only non-black ending
     float* dst = stage + 3ull * (uint32_t)task;
@@ -553,10 +564,6 @@ constexpr uint32_t kGrab = 512;
 struct alignas(16) RaySlot { float px, py, pz, dx; float dy, dz; uint32_t pixel, itk; };
 static_assert(sizeof(RaySlot) == 32, "RaySlot");
 constexpr uint32_t kRing = 128;
-#ifndef TRC_GATHER_MAX
-#define TRC_GATHER_MAX 16
-#endif
-constexpr uint32_t kGatherMax = TRC_GATHER_MAX;   // DevXform records k_queue keeps in LDS (2 KB)
 
 #ifndef TRC_QUEUE_WAVES
 #define TRC_QUEUE_WAVES 5          // resident waves per SIMD the kernel is compiled for
@@ -729,12 +736,13 @@ void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t
   hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, cur, queue_count, counters);
   for (int d = 0; d < kPathDepth; ++d) {
     if (bmp) launch_big_mesh_passes<1>(fp, n_slots, cur, compact ? queue_count + d * kRegions * kCountStride : nullptr, *bmp, stream);
+    const bool lds = fp.sc.n_plane + fp.sc.n_sphere <= kGatherMax;
     if (compact) {
-      hipLaunchKernelGGL(k_bounce<true>, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, next,
+      hipLaunchKernelGGL((lds ? k_bounce<true, true> : k_bounce<true, false>), grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, next,
                          queue_count + d * kRegions * kCountStride, queue_count + (d + 1) * kRegions * kCountStride, stage, counters);
       PathState t = cur; cur = next; next = t;
     } else {
-      hipLaunchKernelGGL(k_bounce<false>, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, cur,
+      hipLaunchKernelGGL((lds ? k_bounce<false, true> : k_bounce<false, false>), grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, cur,
                          (const uint32_t*)nullptr, (uint32_t*)nullptr, stage, counters);
     }
   }
