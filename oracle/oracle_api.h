@@ -57,6 +57,8 @@ const char* orc_name(void);       /* "reference-host-build" or "c-restatement" *
  * TRANS with m_n = 1.6 (BASELINE.json configs[2]).
  * variant 2: walls + light + one MESH icosphere of `param` subdivision levels (configs[4]). */
 void* orc_scene_create(int variant, int param, const char* data_dir);
+/* Wrap an Object[] (reference host layout) built by someone else; records copied, meshes shared. */
+void* orc_scene_wrap(const void* objects, unsigned n);
 void  orc_scene_free(void* scene);
 unsigned orc_scene_size(const void* scene);
 /* pointer to the Object[] array in the reference's host memory layout (Object.inl:24-29,

@@ -66,6 +66,7 @@ class Oracle:
         L.orc_set_math_mode.argtypes = [i32]; L.orc_set_math_mode.restype = i32
         L.orc_scene_create.argtypes = [i32, i32, C.c_char_p]; L.orc_scene_create.restype = vp
         L.orc_scene_free.argtypes = [vp]
+        L.orc_scene_wrap.argtypes = [vp, C.c_uint]; L.orc_scene_wrap.restype = vp
         L.orc_scene_size.argtypes = [vp]; L.orc_scene_size.restype = u32
         L.orc_scene_objects.argtypes = [vp]; L.orc_scene_objects.restype = vp
         L.orc_scene_object_info.argtypes = [vp, u32] + [vp] * 9
@@ -109,6 +110,13 @@ class Oracle:
         s = self.lib.orc_scene_create(variant, param, data_dir.encode())
         if not s:
             raise RuntimeError("orc_scene_create failed")
+        return s
+
+    def scene_wrap(self, objects_ptr, n):
+        """A scene from an Object[] in the reference's host layout built elsewhere (records copied, meshes shared)."""
+        s = self.lib.orc_scene_wrap(objects_ptr, n)
+        if not s:
+            raise RuntimeError("orc_scene_wrap failed")
         return s
 
     def scene_free(self, s):

@@ -183,6 +183,15 @@ void* orc_scene_create(int variant, int param, const char* data_dir) {
   return s;
 }
 
+void* orc_scene_wrap(const void* objects, unsigned n) {
+  if (!objects || n == 0) return NULL;
+  static_assert(sizeof(Object::Object) == 168 && sizeof(Mesh::Mesh) == 72, "reference host layout");
+  RefScene* s = new RefScene;
+  s->objs.resize(n);
+  memcpy((void*)s->objs.data(), objects, sizeof(Object::Object) * n);
+  return s;
+}
+
 void orc_scene_free(void* sc) { delete (RefScene*)sc; }
 unsigned orc_scene_size(const void* sc) { return (unsigned)((const RefScene*)sc)->objs.size(); }
 const void* orc_scene_objects(const void* sc) { return ((const RefScene*)sc)->objs.data(); }

@@ -600,6 +600,18 @@ void* orc_scene_create(int variant, int param, const char* data_dir) {
   return s;
 }
 
+/* A scene built elsewhere: `objects` is an Object[] in the reference's host layout (Object.inl:24-29 with
+ * m_mesh -> Mesh.inl:34-41), e.g. what the product's scene-description API hands to trc_upload_scene. The
+ * records are copied, the meshes they point at are shared and must outlive the scene. */
+void* orc_scene_wrap(const void* objects, unsigned n) {
+  if (!objects || n == 0) return NULL;
+  Scene* s = (Scene*)calloc(1, sizeof(Scene));
+  s->objs = (Object*)malloc(sizeof(Object) * n);
+  memcpy(s->objs, objects, sizeof(Object) * n);
+  s->n = n;
+  return s;
+}
+
 void orc_scene_free(void* sc) { Scene* s = (Scene*)sc; if (s) { free(s->objs); free(s); } }
 unsigned orc_scene_size(const void* sc) { return ((const Scene*)sc)->n; }
 const void* orc_scene_objects(const void* sc) { return ((const Scene*)sc)->objs; }
