@@ -10,7 +10,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 w = int(sys.argv[4]) if len(sys.argv) > 4 else 512
 h = int(sys.argv[5]) if len(sys.argv) > 5 else 512
-sc = ta.Scene(0)
+sc = ta.Scene(int(os.environ.get('TRC_VARIANT', '0')))
 cam = ta.camera_default(w, h)
 tr = ta.Tracer(w, h)
 tr.set_pipeline(pipe)
