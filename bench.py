@@ -70,6 +70,21 @@ def measured_hbm_traffic():
         return None, None
 
 
+def measured_hbm_traffic_compacted():
+    """HBM bytes of one 300-iteration call of the compacted wavefront pipeline (every kernel and fill of the call)
+    from the committed PMC passes (PIPE=1 tools/pmc_hbm.sh -> profiles/*_compacted_hbm_summary.json)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", "*_compacted_hbm_summary.json")))
+    if not files:
+        return None, None
+    try:
+        per = json.load(open(files[-1]))["per_kernel"]
+        mb = sum(v["hbm_read_MB_gfx950_corrected_x2"] + v["hbm_write_MB"] for k, v in per.items() if "tonemap" not in k and "copyBuffer" not in k)
+        return int(mb * 1048576), os.path.basename(files[-1])
+    except (KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline():
     """Time the CPU oracle (plain-C restatement, bit-identical to the reference host build)
     on this box's host cores over a bounded sample of the same workload."""
@@ -193,7 +208,7 @@ def main():
         paths_per_launch = cnt["paths"] / args.steps
         flop = seg_per_launch * FLOP_PER_SEGMENT + paths_per_launch * FLOP_PER_PATH
         achieved = flop / (k_ms * 1e-3) / 1e12
-        kernel_name = {0: "k_bounce<false> (+k_raygen)", 1: "k_bounce<true> (+k_raygen)", 2: "k_fused",
+        kernel_name = {0: "k_bounce<false> (+k_raygen)", 1: "k_bounce<true> (+k_raygen, k_accumulate)", 2: "k_fused",
                        3: "k_queue (+memset, k_accumulate)", 4: "k_queue (+memset, k_accumulate)"}[args.pipeline]
         out = {
             "metric": "Mpath-segments/s, Cornell box 512x512 path trace (mode 2), 300 iterations",
@@ -236,6 +251,13 @@ def main():
         }
         if args.pipeline in (3, 4):
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_hbm_traffic()
+        if args.pipeline == 1:
+            # the per-bounce ray state is the point of this pipeline: its HBM rate against the chip's peak
+            t_bytes, src = measured_hbm_traffic_compacted()
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t_bytes, src
+            if t_bytes:
+                out["roofline"]["hbm_achieved_GBs"] = round(t_bytes / (k_ms * 1e-3) / 1e9, 1)
+                out["roofline"]["hbm_frac"] = round(t_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
         if args.pipeline in (2, 3, 4) and cnt.get("shader_mhz"):
             # FP32 VALU utilisation (the north_star's figure of merit): issue cycles the kernel's VALU
             # instructions need at the best rate the SIMD has, over the cycles it ran -- instruction count
