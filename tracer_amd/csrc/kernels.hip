@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
 // light stores its radiance into a zero-initialised staging buffer stage[iteration][pixel]
 // (12 B per path; 0.94 GB for 512x512x300, nothing against 288 GB of HBM) and
 // k_accumulate adds the staged samples per pixel in iteration order afterwards.
-constexpr uint32_t kGrab = 512;
+constexpr uint32_t kGrab = 512;   // task ids a wavefront reserves at a time (fewer when the whole call is small: launch_queue)
 // One camera ray parked in a wavefront's LDS ring (k_queue).
 struct alignas(16) RaySlot { float px, py, pz, dx; float dy, dz; uint32_t pixel, itk; };
 static_assert(sizeof(RaySlot) == 32, "RaySlot");
@@ -571,7 +571,7 @@ constexpr uint32_t kRing = 128;
 
 template <bool LDS_GATHER>   // the scene's plane + sphere records fit s_xf (the launcher picks the instantiation)
 __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
-                                                    uint32_t n_iters, float* __restrict__ stage,
+                                                    uint32_t n_iters, uint32_t grab, float* __restrict__ stage,
                                                     uint32_t* __restrict__ next_task, DeviceCounters* counters) {
   __shared__ RaySlot s_ring[kMaxWavesPerBlock * kRing];
   RaySlot* __restrict__ ring = s_ring + (threadIdx.x >> 6) * kRing;
@@ -607,11 +607,11 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
       while (ring_count < n_need && !exhausted) {
         if (pool_next == pool_end) {
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(next_task, kGrab);
+          if (lane == 0) base = atomicAdd(next_task, grab);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
           if (base >= total) { exhausted = true; break; }
           pool_next = base;
-          pool_end = (total - base < kGrab) ? total : base + kGrab;
+          pool_end = (total - base < grab) ? total : base + grab;
         }
         const uint32_t avail = pool_end - pool_next;
         const uint32_t take = avail < 64u ? avail : 64u;
@@ -766,8 +766,12 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
   resident_blocks = resident_blocks / 4u * TRC_QUEUE_WAVES;     // CUs x waves per SIMD (a block = 1 wave per SIMD)
   if (blocks > resident_blocks) blocks = resident_blocks;
   const bool lds_gather = fp.sc.n_plane + fp.sc.n_sphere <= kGatherMax;
+  // a small call (an interactive frame: one iteration) is spread over all resident wavefronts: about four
+  // reservations per wavefront, 64 .. kGrab task ids each
+  uint32_t grab = (uint32_t)(paths / ((size_t)blocks * 4u * 4u)) / 64u * 64u;
+  grab = grab < 64u ? 64u : (grab > kGrab ? kGrab : grab);
   hipLaunchKernelGGL(lds_gather ? k_queue<true> : k_queue<false>, dim3(blocks), dim3(kBlock), 0, stream,
-                     fp, iter_first, iter_stride, n_iters, stage, next_task, counters);
+                     fp, iter_first, iter_stride, n_iters, grab, stage, next_task, counters);
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(3u * fp.ntile)), dim3(kBlock), 0, stream,
                      film + 3ull * fp.pix0, (const float*)stage, fp.ntile, n_iters, iter_first == 1u ? 1 : 0);
 }

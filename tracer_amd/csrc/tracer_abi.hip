@@ -509,8 +509,12 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
   HIP_TRY(hipSetDevice(c->device));
   FrameParams fp = make_params(c, cam, seed);
   const uint32_t last_iter = iter_first + (n_iters - 1) * iter_stride;
-  // TRC_PIPE_AUTO: the work queue, unless a big mesh makes the per-bounce brute-force pass worth a launch
-  const int pipeline = c->pipeline != TRC_PIPE_AUTO ? c->pipeline : (c->big.empty() ? TRC_PIPE_QUEUE : TRC_PIPE_COMPACTED);
+  // TRC_PIPE_AUTO: the work queue; the compacted pipeline when a big mesh makes the per-bounce brute-force pass
+  // worth a launch; the fused kernel for a small call (an interactive frame: one iteration of 512x512 takes
+  // 0.07 ms fused, 0.16 ms through the queue; the queue wins from about 1.5 M paths on)
+  const int pipeline = c->pipeline != TRC_PIPE_AUTO ? c->pipeline
+                     : !c->big.empty() ? TRC_PIPE_COMPACTED
+                     : (uint64_t)fp.ntile * n_iters <= 1500000ull ? TRC_PIPE_FUSED : TRC_PIPE_QUEUE;
   BigMeshPass bmp = {};
   const BigMeshPass* pass = nullptr;
   const bool wave = pipeline == TRC_PIPE_WAVEFRONT || pipeline == TRC_PIPE_COMPACTED;
