@@ -152,8 +152,13 @@ def main():
     # scene + camera through the product's own host API (no oracle here)
     scene = ta.Scene(0)
     cam = ta.camera_default(W, H)
-    stream = torch.cuda.current_stream().cuda_stream
-    tr = ta.Tracer(W, H, device=local_rank, stream=stream)
+    # ONE stream for everything: torch's zero_(), the tracer's launches and the RCCL reduce are then ordered by
+    # the stream itself. (torch's default stream has handle 0, which trc_create takes as "make a private
+    # stream" -- the film sum would not wait for the render.)
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    assert work_stream.cuda_stream != 0
+    tr = ta.Tracer(W, H, device=local_rank, stream=work_stream.cuda_stream)
     tr.set_pipeline(args.pipeline)
     tr.upload_scene(scene.objects_ptr, scene.size)
     film = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)   # torch owns the film so RCCL can reduce it
@@ -188,6 +193,19 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     cnt = tr.counters()
+
+    # Untimed self-check of the multi-GPU path: the reduced film holds world x ITERS samples per pixel, so its
+    # mean per sample must agree with the mean of rank 0's own ITERS samples (a sum that did not wait for a
+    # rank's render, or lost a rank, would not).
+    film_check = None
+    if world > 1:
+        step(); torch.cuda.synchronize()
+        mean_all = float(film.sum().item()) / (3.0 * W * H * ITERS * world) if rank == 0 else 0.0
+        film.zero_(); tr.pathtrace(cam, SEED, rank + 1, ITERS, iter_stride=world); torch.cuda.synchronize()
+        mean_own = float(film.sum().item()) / (3.0 * W * H * ITERS)
+        if rank == 0:
+            film_check = {"mean_radiance_all_ranks": round(mean_all, 6), "mean_radiance_rank0": round(mean_own, 6),
+                          "ok": bool(abs(mean_all - mean_own) <= 0.01 * mean_own)}
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -273,6 +291,8 @@ def main():
                 out["roofline"]["valu_insts_per_64_segments"] = per64
                 out["roofline"]["valu_insts_source"] = src
                 out["roofline"]["valu_issue_utilisation"] = round(insts_per_simd * VALU_ISSUE_CYCLES / cycles, 4)
+        if film_check is not None:
+            out["film_check"] = film_check
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
