@@ -93,17 +93,38 @@ __device__ __forceinline__ Ray camera_sample(const FrameParams& fp, uint32_t idx
   return ray;
 }
 
+// SGPR pressure. A persistent kernel that keeps all of FrameParams (68 dwords of kernel arguments) in SGPRs
+// for its whole loop leaves too few for the loop body, and the register allocator parks the overflow in the
+// lanes of a VGPR: every later use is a v_readlane -- a VALU instruction in a VALU-bound kernel (k_queue:
+// ~100 of them per trip). Fields that a part of the loop needs are instead read again from the
+// kernel-argument segment right there: s_load, scalar cache, no VALU. The empty asm makes the address opaque
+// so that the optimiser does not hoist the loads back out of the loop.
+// Only for kernels whose argument 0 is the FrameParams.
+__device__ __forceinline__ const FrameParams* kernarg_params() {
+  unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  return reinterpret_cast<const FrameParams*>(ka);
+}
+
 // ---- one bounce (calcColorKernel body, raytrace.cu:126-159) -------------------------------------
 // Wave-convergent: every lane of the wavefront calls it; lanes with live == false run along
 // (their result is STEP_IDLE and their ray/col are left untouched).
 enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE = 3 };
 
-__device__ __forceinline__ int bounce_step(const FrameParams& fp, bool live, uint32_t pixel, uint32_t iter, int depth,
+// `fp_is_arg0`: the calling kernel's argument 0 is this FrameParams (see kernarg_params()).
+__device__ __forceinline__ int bounce_step(const FrameParams& fp_in, bool live, uint32_t pixel, uint32_t iter, int depth,
                                            Ray& ray, f3& col, uint32_t& tri_tests, uint32_t slot = 0u,
-                                           const DevXform* __restrict__ gather = nullptr, bool gather_given = false) {
-  Hit hit = closest_hit(ray, live, fp.sc, tri_tests, slot, gather_given ? gather : fp.sc.xf);
+                                           const DevXform* __restrict__ gather = nullptr, bool gather_given = false,
+                                           bool fp_is_arg0 = false) {
+  DevScene sc_again;
+  if (fp_is_arg0) sc_again = load_uniform(&kernarg_params()->sc);
+  const DevScene& sc = fp_is_arg0 ? sc_again : fp_in.sc;
+  Hit hit = closest_hit(ray, live, sc, tri_tests, slot, gather_given ? gather : sc.xf);
   if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
+  FrameParams again;
+  if (fp_is_arg0) again = load_uniform(kernarg_params());
+  const FrameParams& fp = fp_is_arg0 ? again : fp_in;
   const DevMaterial& o = fp.sc.mats[hit.id];
   const f3 mcolor = o.color;
   const float emit = o.emit;
@@ -569,10 +590,18 @@ constexpr uint32_t kRing = 128;
 #define TRC_QUEUE_WAVES 5          // resident waves per SIMD the kernel is compiled for
 #endif
 
+// All of k_queue's arguments as one struct (FrameParams first: kernarg_params()), so that the loop can read any
+// of them again from the kernel-argument segment where it needs it.
+struct QueueArgs {
+  FrameParams fp;
+  uint32_t iter_first, iter_stride, total, grab;   // total = tile pixels x iterations = number of path tasks
+  float* stage; uint32_t* next_task; DeviceCounters* counters;
+};
+__device__ __forceinline__ const QueueArgs* kernarg_queue() { return reinterpret_cast<const QueueArgs*>(kernarg_params()); }
+
 template <bool LDS_GATHER>   // the scene's plane + sphere records fit s_xf (the launcher picks the instantiation)
-__global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
-                                                    uint32_t n_iters, uint32_t grab, float* __restrict__ stage,
-                                                    uint32_t* __restrict__ next_task, DeviceCounters* counters) {
+__global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa) {
+  const FrameParams& fp = qa.fp;
   __shared__ RaySlot s_ring[kMaxWavesPerBlock * kRing];
   RaySlot* __restrict__ ring = s_ring + (threadIdx.x >> 6) * kRing;
   // The plane / sphere records that held candidates gather per lane (intersect.h: flush_held), copied to LDS once.
@@ -583,7 +612,6 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
     for (uint32_t i = threadIdx.x; i < n_dw; i += kBlock) ((uint32_t*)s_xf)[i] = ((const uint32_t*)fp.sc.xf)[i];
     __syncthreads();
   }
-  const uint32_t total = fp.ntile * n_iters;
   const unsigned lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: task ids this wave has reserved
@@ -605,9 +633,11 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
       // here, so at most 127 of its kRing = 128 slots are ever in use); finished lanes then just pick
       // one up. Generating only for the lanes that happen to be idle ran this code at ~27 % lane use.
       while (ring_count < n_need && !exhausted) {
+        const QueueArgs* ka = kernarg_queue();
         if (pool_next == pool_end) {
+          const uint32_t grab = load_uniform(&ka->grab), total = load_uniform(&ka->total);
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(next_task, grab);
+          if (lane == 0) base = atomicAdd(load_uniform(&ka->next_task), grab);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
           if (base >= total) { exhausted = true; break; }
           pool_next = base;
@@ -617,10 +647,13 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
         const uint32_t take = avail < 64u ? avail : 64u;
         const bool gen = lane < take;
         TRC_MARK("regen");
+        // the camera and image fields are needed only here, once per 64 new paths (see kernarg_params())
+        const FrameParams cf = load_uniform(&ka->fp);
         uint32_t g_pixel;
-        const uint32_t g_itk = udivmod(gen ? pool_next + lane : 0u, fp.div_tile, g_pixel);
-        g_pixel += fp.pix0;
-        const Ray g = camera_sample(fp, g_pixel, iter_first + g_itk * iter_stride, TRC_UCMP(lane, take, I_ULT));
+        const uint32_t g_itk = udivmod(gen ? pool_next + lane : 0u, cf.div_tile, g_pixel);
+        g_pixel += cf.pix0;
+        const Ray g = camera_sample(cf, g_pixel, load_uniform(&ka->iter_first) + g_itk * load_uniform(&ka->iter_stride),
+                                    TRC_UCMP(lane, take, I_ULT));
         if (gen) {
           RaySlot& o = ring[(ring_head + ring_count + lane) & (kRing - 1u)];
           o.px = g.pos.x; o.py = g.pos.y; o.pz = g.pos.z; o.dx = g.dir.x; o.dy = g.dir.y; o.dz = g.dir.z;
@@ -635,7 +668,8 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
         const RaySlot& o = ring[(ring_head + rank) & (kRing - 1u)];
         ray.pos = mk3(o.px, o.py, o.pz); ray.dir = mk3(o.dx, o.dy, o.dz);
         pixel = o.pixel; itk = o.itk;
-        iter = iter_first + itk * iter_stride;
+        const QueueArgs* ka = kernarg_queue();
+        iter = load_uniform(&ka->iter_first) + itk * load_uniform(&ka->iter_stride);
         col = splat3(1.0f);
         depth = 0;
         have = true;
@@ -646,20 +680,22 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(FrameParams f
       ring_count -= taken;
     }
     if (__ballot(have) == 0ull) break;
-    const int res = LDS_GATHER ? bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, s_xf, true)
-                               : bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, fp.sc.xf, true);
+    const int res = LDS_GATHER ? bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, s_xf, true, true)
+                               : bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, fp.sc.xf, true, true);
     TRC_MARK("bounce_done");
     if (res == STEP_CONTINUE) {
       ++live; ++depth;
     } else if (res != STEP_IDLE) {
       ++live;
       if (res == STEP_LIGHT) {                                        // black endings add nothing
-        float* dst = stage + 3ull * ((unsigned long long)itk * fp.ntile + (pixel - fp.pix0));
+        const QueueArgs* ka = kernarg_queue();
+        float* dst = load_uniform(&ka->stage) + 3ull * ((unsigned long long)itk * load_uniform(&ka->fp.ntile) + (pixel - load_uniform(&ka->fp.pix0)));
         dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
       }
       have = false;
     }
   }
+  DeviceCounters* counters = load_uniform(&kernarg_queue()->counters);
   count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, (unsigned long long)live);
   count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
   count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, (unsigned long long)paths);
@@ -770,8 +806,10 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
   // reservations per wavefront, 64 .. kGrab task ids each
   uint32_t grab = (uint32_t)(paths / ((size_t)blocks * 4u * 4u)) / 64u * 64u;
   grab = grab < 64u ? 64u : (grab > kGrab ? kGrab : grab);
-  hipLaunchKernelGGL(lds_gather ? k_queue<true> : k_queue<false>, dim3(blocks), dim3(kBlock), 0, stream,
-                     fp, iter_first, iter_stride, n_iters, grab, stage, next_task, counters);
+  QueueArgs qa;
+  qa.fp = fp; qa.iter_first = iter_first; qa.iter_stride = iter_stride; qa.total = (uint32_t)paths; qa.grab = grab;
+  qa.stage = stage; qa.next_task = next_task; qa.counters = counters;
+  hipLaunchKernelGGL((lds_gather ? k_queue<true> : k_queue<false>), dim3(blocks), dim3(kBlock), 0, stream, qa);
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(3u * fp.ntile)), dim3(kBlock), 0, stream,
                      film + 3ull * fp.pix0, (const float*)stage, fp.ntile, n_iters, iter_first == 1u ? 1 : 0);
 }
