@@ -540,13 +540,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
     if (!done && need_new) {
       iter = iter_first + k * iter_stride;
       if (iter == 1) acc = splat3(0.0f);                              // raytrace.cu:103-104
-      ray = camera_sample(fp, pixel, iter);
+      const FrameParams cf = load_uniform(kernarg_params());          // camera fields: see kernarg_params()
+      ray = camera_sample(cf, pixel, iter);
       col = splat3(1.0f);
       depth = 0;
       need_new = false;
     }
     if (__ballot(!done) == 0ull) break;
-    const int res = bounce_step(fp, !done, pixel, iter, depth, ray, col, tt);
+    const int res = bounce_step(fp, !done, pixel, iter, depth, ray, col, tt, 0u, nullptr, false, true);
     if (res == STEP_CONTINUE) {
       ++live; ++depth;
     } else if (res != STEP_IDLE) {
