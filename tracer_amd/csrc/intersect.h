@@ -72,10 +72,23 @@ __device__ __forceinline__ Hit no_hit() {   // Ray.inl:30  Hit() : m_t(-1), m_id
   Hit h; h.t = -1.0f; h.id = -1; h.pos = splat3(0.0f); h.nor = splat3(0.0f); return h;
 }
 
-// Ray.inl:50-57: two point transforms, direction RE-normalised in object space
+// The vector-side condition of sparse_xform.h: the lanes whose six coordinates are all finite and in
+// [2^-60, 2^60) (the sum catches NaN, inf and big values; v_min skips NaNs, which the sum has already caught).
+__device__ __forceinline__ lmask coords_ok(f3 a, f3 b) {
+  const float sum = __builtin_fabsf(a.x) + __builtin_fabsf(a.y) + __builtin_fabsf(a.z) +
+                    __builtin_fabsf(b.x) + __builtin_fabsf(b.y) + __builtin_fabsf(b.z);
+  const float la = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+  const float lb = __builtin_fminf(__builtin_fminf(__builtin_fabsf(b.x), __builtin_fabsf(b.y)), __builtin_fabsf(b.z));
+  return TRC_FCMP(sum, 0x1p60f, F_OLT) & TRC_FCMP(__builtin_fminf(la, lb), 0x1p-60f, F_OGE);
+}
+
+// Ray.inl:50-57: two point transforms, direction RE-normalised in object space.
+// P: a zero pattern of `mi` (sparse_xform.h). Anything but XP_FULL requires coords_ok(ray.pos, ray.pos + ray.dir)
+// for every lane of `live`.
+template <uint32_t P = XP_FULL>
 __device__ __forceinline__ Ray to_object_space(const Ray& ray, const Affine& mi, lmask live) {
-  f3 pos = xform_point(mi, ray.pos);
-  f3 point = xform_point(mi, ray.pos + ray.dir);
+  f3 pos = xform_point_sparse<P>(mi, ray.pos);
+  f3 point = xform_point_sparse<P>(mi, ray.pos + ray.dir);
   Ray r; r.pos = pos; r.dir = normalize_dev(point - pos, live);
   return r;
 }
@@ -301,12 +314,12 @@ __device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform*
 
 // K planes at once. Ray.inl:142-158: t = -o.y/d.y, hit iff |x|,|z| < 0.5 (strict); the normal is
 // always object +y -> DevXform::nor_y. Only t > 0 competes (Ray.inl:72).
-template <int K>
+template <int K, uint32_t P>
 __device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
                                        const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, load_uniform(&xf[first + k].mi), live);    // Ray.inl:88
+  for (int k = 0; k < K; ++k) r[k] = to_object_space<P>(ray, load_uniform(&xf[first + k].mi), live);    // Ray.inl:88
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const float tp = -r[k].pos.y / r[k].dir.y;
@@ -318,12 +331,12 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, c
 
 // K spheres at once. Ray.inl:103-118: radius 0.5, geometric method, normal = normalize(pos),
 // then Ray.inl:62 normalize(M * (n, 0)) -- both only for a held candidate (flush_held).
-template <int K>
+template <int K, uint32_t P>
 __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
                                         const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space(ray, load_uniform(&xf[first + k].mi), live);
+  for (int k = 0; k < K; ++k) r[k] = to_object_space<P>(ray, load_uniform(&xf[first + k].mi), live);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const f3 l = -r[k].pos;
@@ -339,12 +352,29 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, lmask live, 
   }
 }
 
+// objects [lo, hi) of the group, two per trip
+template <uint32_t P>
+__device__ __forceinline__ void planes_range(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
+                                             const DevXform* __restrict__ xg, uint32_t lo, uint32_t hi, Held& h) {
+  uint32_t i = lo;
+  for (; i + 2 <= hi; i += 2) planes<2, P>(c, ray, live, xf, xg, i, h);
+  if (i < hi) planes<1, P>(c, ray, live, xf, xg, i, h);
+}
+template <uint32_t P>
+__device__ __forceinline__ void spheres_range(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
+                                              const DevXform* __restrict__ xg, uint32_t lo, uint32_t hi, Held& h) {
+  uint32_t i = lo;
+  for (; i + 2 <= hi; i += 2) spheres<2, P>(c, ray, live, xf, xg, i, h);
+  if (i < hi) spheres<1, P>(c, ray, live, xf, xg, i, h);
+}
+
 // Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
 // -x,+x,-y,+y,-z,else +z, taken from the per-object table of world normals.
+template <uint32_t P>
 __device__ __forceinline__ void cube(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g, const DevCubeExtra& ex_g) {
   const DevXform xf = load_uniform(&xf_g);
   const DevCubeExtra ex = load_uniform(&ex_g);
-  const Ray r = to_object_space(ray, xf.mi, live);
+  const Ray r = to_object_space<P>(ray, xf.mi, live);
   float tNear, tFar;
   const bool hit = lane_of(slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar, live));
   const float th = tNear > 0.0f ? tNear : tFar;
@@ -409,18 +439,29 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const
   const DevXform* __restrict__ xg = gather;
   uint32_t i = 0;
   Held h; h.any = 0ull; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u;
+  // Within a type the objects are sorted by the zero pattern of their m_matrixi (scene.h): one straight-line
+  // loop body per pattern. A wavefront with a ray that fails the vector-side condition of sparse_xform.h takes
+  // every object through the full product.
+  const bool sparse = (live & ~coords_ok(ray.pos, ray.pos + ray.dir)) == 0ull;
   TRC_MARK("planes");
-  for (; i + 2 <= sc.n_plane; i += 2) planes<2>(c, ray, live, xf, xg, i, h);
-  if (i < sc.n_plane) planes<1>(c, ray, live, xf, xg, i, h);
+  planes_range<XP_FULL>(c, ray, live, xf, xg, 0u, sparse ? sc.plane_end[XP_FULL] : sc.n_plane, h);
+  if (sparse) {
+    planes_range<XP_DIAG>(c, ray, live, xf, xg, sc.plane_end[XP_FULL], sc.plane_end[XP_DIAG], h);
+    planes_range<XP_BLOCK_X>(c, ray, live, xf, xg, sc.plane_end[XP_DIAG], sc.plane_end[XP_BLOCK_X], h);
+    planes_range<XP_BLOCK_Y>(c, ray, live, xf, xg, sc.plane_end[XP_BLOCK_X], sc.plane_end[XP_BLOCK_Y], h);
+    planes_range<XP_BLOCK_Z>(c, ray, live, xf, xg, sc.plane_end[XP_BLOCK_Y], sc.n_plane, h);
+  }
   flush_held<false>(c, ray, xg, h);
   xf += sc.n_plane; xg += sc.n_plane;
   TRC_MARK("spheres");
-  for (i = 0; i + 2 <= sc.n_sphere; i += 2) spheres<2>(c, ray, live, xf, xg, i, h);
-  if (i < sc.n_sphere) spheres<1>(c, ray, live, xf, xg, i, h);
+  spheres_range<XP_FULL>(c, ray, live, xf, xg, 0u, sparse ? sc.sphere_full : sc.n_sphere, h);
+  if (sparse) spheres_range<XP_DIAG>(c, ray, live, xf, xg, sc.sphere_full, sc.n_sphere, h);
   flush_held<true>(c, ray, xg, h);
   xf += sc.n_sphere;
   TRC_MARK("cubes");
-  for (i = 0; i < sc.n_cube; ++i) cube(c, ray, live, xf[i], sc.cubes[i]);
+  const uint32_t cube_full = sparse ? sc.cube_full : sc.n_cube;
+  for (i = 0; i < cube_full; ++i) cube<XP_FULL>(c, ray, live, xf[i], sc.cubes[i]);
+  for (; i < sc.n_cube; ++i) cube<XP_DIAG>(c, ray, live, xf[i], sc.cubes[i]);
   xf += sc.n_cube;
   TRC_MARK("meshes");
   for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc, slot, tri_tests);

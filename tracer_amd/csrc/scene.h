@@ -2,6 +2,7 @@
 // pointer-based AoS) and as the kernels read it (flat, pointer-free, wave-uniform records).
 #pragma once
 #include "vecmath.h"
+#include "sparse_xform.h"
 
 namespace trc {
 
@@ -62,14 +63,16 @@ static_assert(sizeof(DevObject) == 240, "DevObject");
 // Every lane of a wavefront walks the same object list (Ray.inl:70), so a record is read with
 // wave-uniform scalar loads into SGPRs; grouping lets the kernel run type-specialised,
 // branch-free loops that test two objects of one type per trip (two independent dependency
-// chains for the VALU to interleave). The reference's tie rule "lowest object index wins"
+// chains for the VALU to interleave), and sorting a group by the zero pattern of the matrices lets the
+// loop body leave out the multiplications by exact zeros (sparse_xform.h). The reference's tie rule "lowest object index wins"
 // (strict `<` in index order, Ray.inl:75) is kept by comparing (distance, original index).
 struct alignas(16) DevXform {      // 128 bytes = two s_load_dwordx16
   Affine   mi;                     // world -> object (Object::m_matrixi)
   Affine   m;                      // object -> world (Object::m_matrix)
   f3       nor_y;                  // world normal of object-space +y: what a PLANE hit reports
   uint32_t id;                     // index in the caller's Object[] (Hit::m_id)
-  uint32_t pad[4];
+  uint32_t mi_pat;                 // XformPattern of mi this object is filed under (sparse_xform.h)
+  uint32_t pad[3];
 };
 static_assert(sizeof(DevXform) == 128, "DevXform");
 struct alignas(16) DevCubeExtra { f3 axis_nor[6]; float pad[2]; };                 // 80 bytes
@@ -105,6 +108,11 @@ struct DevScene {
   // persistent pipelines, which test big meshes inside closest_hit() like small ones.
   const unsigned long long* mesh_keys;
   uint32_t key_stride, n_big;
+  // Within a type the records are sorted by the zero pattern of mi (XformPattern order: FULL, DIAG, BLOCK_X,
+  // BLOCK_Y, BLOCK_Z), so that the kernels run one specialised loop per pattern. plane_end[P] = end of pattern
+  // P's run among the planes (BLOCK_Z's ends at n_plane); spheres and cubes distinguish FULL | DIAG only;
+  // meshes are not sorted (always the full product).
+  uint32_t plane_end[4], sphere_full, cube_full;
 };
 
 // Triangle stream: faces pre-gathered at upload (replaces the Face -> verts/norms double

@@ -255,6 +255,15 @@ int flatten_scene(const RefObject* objs, uint32_t count, std::vector<DevObject>&
   return TRC_OK;
 }
 
+// The zero pattern of m_matrixi an object is filed under (scene.h: DevScene::plane_end): planes use all five,
+// spheres and cubes FULL | DIAG, meshes FULL.
+uint32_t filed_pattern(const DevObject& o) {
+  const uint32_t pat = classify_xform(o.mi);
+  if (o.mesh_type == REF_PLANE) return pat;
+  if (o.mesh_type == REF_MESH) return XP_FULL;
+  return pat == XP_DIAG ? XP_DIAG : XP_FULL;
+}
+
 // Group the flattened objects by primitive type and lay everything out in one buffer
 // (scene.h: DevScene). `base` is the device address the buffer will live at.
 size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>& tris,
@@ -265,11 +274,13 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
   std::vector<DevMaterial> mats(objs.size());
   const int order[4] = { REF_PLANE, REF_SPHERE, REF_CUBE, REF_MESH };
   for (int g = 0; g < 4; ++g)
+   for (uint32_t pat = XP_FULL; pat <= XP_BLOCK_Z; ++pat)            // within a type: sorted by filed_pattern()
     for (size_t i = 0; i < objs.size(); ++i) {
       const DevObject& o = objs[i];
-      if (o.mesh_type != order[g]) continue;
+      if (o.mesh_type != order[g] || filed_pattern(o) != pat) continue;
       DevXform x; memset(&x, 0, sizeof x);
       x.mi = o.mi; x.m = o.m; x.nor_y = o.axis_nor[3]; x.id = (uint32_t)i;
+      x.mi_pat = pat;
       xf.push_back(x);
       if (o.mesh_type == REF_CUBE) {
         DevCubeExtra e; memset(&e, 0, sizeof e);
@@ -323,10 +334,15 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
 
 DevScene scene_pointers(const std::vector<DevObject>& objs, const std::vector<DevTri>& tris, void* base) {
   DevScene sc; memset(&sc, 0, sizeof sc);
+  uint32_t plane_pat[5] = { 0, 0, 0, 0, 0 };
   for (const DevObject& o : objs) {
-    if (o.mesh_type == REF_PLANE) ++sc.n_plane; else if (o.mesh_type == REF_SPHERE) ++sc.n_sphere;
-    else if (o.mesh_type == REF_CUBE) ++sc.n_cube; else ++sc.n_mesh;
+    const uint32_t pat = filed_pattern(o);
+    if (o.mesh_type == REF_PLANE) { ++sc.n_plane; ++plane_pat[pat]; }
+    else if (o.mesh_type == REF_SPHERE) { ++sc.n_sphere; sc.sphere_full += pat == XP_FULL; }
+    else if (o.mesh_type == REF_CUBE) { ++sc.n_cube; sc.cube_full += pat == XP_FULL; }
+    else ++sc.n_mesh;
   }
+  for (uint32_t pat = XP_FULL, end = 0; pat < XP_BLOCK_Z; ++pat) { end += plane_pat[pat]; sc.plane_end[pat] = end; }
   auto up = [](size_t n) { return (n + 255) & ~size_t(255); };
   unsigned char* p = (unsigned char*)base;
   sc.xf = (const DevXform*)p;         p += up(objs.size() * sizeof(DevXform));
