@@ -64,9 +64,10 @@ def measured_hbm_traffic():
     if not files:
         return None, None
     try:
-        k = json.load(open(files[-1]))["per_kernel"]["trc::k_queue"]
+        per = json.load(open(files[-1]))["per_kernel"]
+        k = next(v for name, v in per.items() if "k_queue" in name)
         return int((k["hbm_read_MB_gfx950_corrected_x2"] + k["hbm_write_MB"]) * 1048576), os.path.basename(files[-1])
-    except (KeyError, ValueError):
+    except (KeyError, ValueError, StopIteration):
         return None, None
 
 
