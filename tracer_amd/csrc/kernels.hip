@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
 // different cost), whatever the image size.
 // The reference sums a pixel's samples in iteration order (raytrace.cu:170). To keep that sum
 // bit-exact although samples now finish in any order on any lane, a path that reaches the
-// light stores its radiance into a zero-initialised staging buffer stage[iteration][pixel]
+// light stores its radiance -- every other path a zero -- into a staging buffer stage[iteration][pixel]
 // (12 B per path; 0.94 GB for 512x512x300, nothing against 288 GB of HBM) and
 // k_accumulate adds the staged samples per pixel in iteration order afterwards.
 constexpr uint32_t kGrab = 512;   // task ids a wavefront reserves at a time (fewer when the whole call is small: launch_queue)
@@ -688,11 +688,12 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
       ++live; ++depth;
     } else if (res != STEP_IDLE) {
       ++live;
-      if (res == STEP_LIGHT) {                                        // black endings add nothing
-        const QueueArgs* ka = kernarg_queue();
-        float* dst = load_uniform(&ka->stage) + 3ull * ((unsigned long long)itk * load_uniform(&ka->fp.ntile) + (pixel - load_uniform(&ka->fp.pix0)));
-        dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
-      }
+      // Every path writes its sample when it ends -- the radiance it carried to the light, or the zero that
+      // bounce_step() left in `col` for a miss or the depth cap -- so the staging buffer needs no clearing
+      // (some lane of a wavefront reaches the light on nine trips out of ten: the stores were issued anyway).
+      const QueueArgs* ka = kernarg_queue();
+      float* dst = load_uniform(&ka->stage) + 3ull * ((unsigned long long)itk * load_uniform(&ka->fp.ntile) + (pixel - load_uniform(&ka->fp.pix0)));
+      dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
       have = false;
     }
   }
@@ -797,8 +798,7 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
                   float* film, float* stage, uint32_t* next_task, unsigned resident_blocks,
                   DeviceCounters* counters, hipStream_t stream) {
   const size_t paths = (size_t)fp.ntile * n_iters;
-  (void)hipMemsetAsync(stage, 0, sizeof(float) * 3ull * paths, stream);
-  (void)hipMemsetAsync(next_task, 0, sizeof(uint32_t), stream);
+  (void)hipMemsetAsync(next_task, 0, sizeof(uint32_t), stream);       // (k_queue writes every sample of `stage`)
   unsigned blocks = (unsigned)((paths + kBlock - 1) / kBlock);
   resident_blocks = resident_blocks / 4u * TRC_QUEUE_WAVES;     // CUs x waves per SIMD (a block = 1 wave per SIMD)
   if (blocks > resident_blocks) blocks = resident_blocks;
