@@ -716,7 +716,16 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(float* __restrict__ film,
   float f = restart ? 0.0f : film[idx];
   const float* s = stage + idx;
   const size_t pitch = 3ull * npix;
-  for (uint32_t k = 0; k < n_iters; ++k) f = f + s[k * pitch];
+  // the additions are a serial chain; the loads are not: 16 in flight per lane
+  uint32_t k = 0;
+  for (; k + 16 <= n_iters; k += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(&s[(k + j) * pitch]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f = f + v[j];
+  }
+  for (; k < n_iters; ++k) f = f + s[k * pitch];
   film[idx] = f;
 }
 
