@@ -228,7 +228,7 @@ def main():
         flop = seg_per_launch * FLOP_PER_SEGMENT + paths_per_launch * FLOP_PER_PATH
         achieved = flop / (k_ms * 1e-3) / 1e12
         kernel_name = {0: "k_bounce<false> (+k_raygen)", 1: "k_bounce<true> (+k_raygen, k_accumulate)", 2: "k_fused",
-                       3: "k_queue (+memset, k_accumulate)", 4: "k_queue (+memset, k_accumulate)"}[args.pipeline]
+                       3: "k_queue (+k_accumulate)", 4: "k_queue (+k_accumulate)"}[args.pipeline]
         out = {
             "metric": "Mpath-segments/s, Cornell box 512x512 path trace (mode 2), 300 iterations",
             "value": round(value, 2),
