@@ -189,6 +189,10 @@ struct alignas(16) MeshSlot {
 };
 static_assert(sizeof(MeshSlot) == 48, "MeshSlot");
 constexpr int kMaxWavesPerBlock = 4;
+#ifndef TRC_MESH_SLOTS
+#define TRC_MESH_SLOTS 64          // mailboxes per wavefront; with fewer than 64, mesh_closest() takes the passing rays in rounds
+#endif
+static_assert(TRC_MESH_SLOTS >= 1 && TRC_MESH_SLOTS <= 64, "TRC_MESH_SLOTS");
 
 // MESH, Ray.inl:160-186: brute force over the object's triangles in face order, strict `<`
 // (lowest face index wins ties, Ray.inl:174). Wave-convergent; `pass` marks the lanes whose
@@ -201,23 +205,29 @@ constexpr int kMaxWavesPerBlock = 4;
 // slot and the ray's own lane collects (t, normal) at the end.
 __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const DevTri* __restrict__ tris,
                                               const DevMeshExtra& ex, f3& bn, uint32_t& tri_tests) {
-  __shared__ MeshSlot s_slots[kMaxWavesPerBlock * 64];
+  __shared__ MeshSlot s_slots[kMaxWavesPerBlock * TRC_MESH_SLOTS];
   const uint32_t first = ex.tri_first, count = ex.tri_count;
   float best = FLT_MAX;
   bn = splat3(0.0f);
   if (mask == 0ull || count == 0u) return best;
-  const bool pass = lane_of(mask);
-  const unsigned n_pass = __popcll(mask);
-  if (pass) tri_tests += count;
+  if (lane_of(mask)) tri_tests += count;
   const unsigned lane = lane_id();
   const unsigned G = count < 64u ? count : 64u;                  // triangles side by side in one pass
   const unsigned R = ex.rays_per_pass;                           // 64 / G rays side by side
   const unsigned n_chunks = (count + 63u) >> 6;
+  lmask todo = mask;
+  do {
+  // this round: the first TRC_MESH_SLOTS passing rays that are still to do (all of them when there are 64 mailboxes)
+  lmask round = todo;
+  if (TRC_MESH_SLOTS < 64) round = todo & TRC_UCMP((unsigned)__popcll(todo & ((1ull << lane) - 1ull)), (unsigned)TRC_MESH_SLOTS, I_ULT);
+  todo &= ~round;
+  const bool pass = lane_of(round);
+  const unsigned n_pass = __popcll(round);
   // cost model (VALU instructions per wave): pair enumeration ~ ceil(n_pass / R) * n_chunks * 110,
   // ray-per-lane ~ count * 95
   if (((n_pass + R - 1u) / R) * n_chunks * 5u <= count * 4u) {
-    MeshSlot* __restrict__ slots = s_slots + (threadIdx.x >> 6) * 64;
-    const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+    MeshSlot* __restrict__ slots = s_slots + (threadIdx.x >> 6) * TRC_MESH_SLOTS;
+    const unsigned rank = __popcll(round & ((1ull << lane) - 1ull));      // < n_pass <= TRC_MESH_SLOTS
     const unsigned long long KEY_NONE = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // t = FLT_MAX
     if (pass) {
       MeshSlot& m = slots[rank];
@@ -260,6 +270,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
       if (t > 0.0f && t < best) { best = t; bn = n; }
     }
   }
+  } while (todo != 0ull);
   return best;
 }
 
