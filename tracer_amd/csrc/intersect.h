@@ -335,7 +335,8 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, c
   for (int k = 0; k < K; ++k) {
     const float tp = -r[k].pos.y / r[k].dir.y;
     const f3 p = r[k].pos + tp * r[k].dir;
-    const lmask in = TRC_FCMP(p.x, 0.5f, F_OLT) & TRC_FCMP(p.z, 0.5f, F_OLT) & TRC_FCMP(p.x, -0.5f, F_OGT) & TRC_FCMP(p.z, -0.5f, F_OGT);
+    // Ray.inl:148-149  x < 0.5 && x > -0.5 is |x| < 0.5 for every float (NaN fails both forms); |.| is a source modifier
+    const lmask in = TRC_FCMP(__builtin_fabsf(p.x), 0.5f, F_OLT) & TRC_FCMP(__builtin_fabsf(p.z), 0.5f, F_OLT);
     hold<false>(c, ray, xg, h, live & in & TRC_FCMP(tp, 0.0f, F_OGT), tp, p, first + k);
   }
 }
