@@ -37,7 +37,7 @@ __device__ __forceinline__ bool lane_of(lmask m) { return __builtin_amdgcn_inver
 // `need` = the lanes whose result is observable (dead / masked lanes must not force the slow path).
 __device__ __forceinline__ float cr_rsqrt(float s, lmask need) {
   const lmask ok = TRC_UCMP(__float_as_uint(s) - 0x0D000000u, 0x7E800000u - 0x0D000000u, I_ULT);   // 2^-101 <= s < 2^126
-  if ((need & ~ok) == 0ull) {
+  if (__builtin_expect((need & ~ok) == 0ull, 1)) {
     const float y = __builtin_amdgcn_rsqf(s);
     const float q0 = s * y;
     const float h = 0.5f * y;
@@ -49,7 +49,7 @@ __device__ __forceinline__ float cr_rsqrt(float s, lmask need) {
 }
 __device__ __forceinline__ float cr_sqrt(float s, lmask need) {
   const lmask ok = TRC_UCMP(__float_as_uint(s) - 0x0D000000u, 0x7F800000u - 0x0D000000u, I_ULT);   // 2^-101 <= s < inf
-  if ((need & ~ok) == 0ull) {
+  if (__builtin_expect((need & ~ok) == 0ull, 1)) {
     const float y = __builtin_amdgcn_rsqf(s);
     const float q0 = s * y;
     const float h = 0.5f * y;
@@ -59,7 +59,7 @@ __device__ __forceinline__ float cr_sqrt(float s, lmask need) {
 }
 __device__ __forceinline__ float cr_rcp(float x, lmask need) {
   const lmask ok = TRC_UCMP((__float_as_uint(x) & 0x7FFFFFFFu) - 0x00800000u, 0x7E800000u - 0x00800000u, I_ULT); // normal, |x| < 2^126
-  if ((need & ~ok) == 0ull) {
+  if (__builtin_expect((need & ~ok) == 0ull, 1)) {
     const float r0 = __builtin_amdgcn_rcpf(x);
     return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
   }

@@ -136,7 +136,7 @@ __device__ __forceinline__ lmask slab(const Ray& ray, f3 bmin, f3 bmax, float& t
   const float hi = __builtin_fmaxf(max3f(__builtin_fabsf(a0.x), __builtin_fabsf(a0.y), __builtin_fabsf(a0.z)),
                                    max3f(__builtin_fabsf(a1.x), __builtin_fabsf(a1.y), __builtin_fabsf(a1.z)));
   const lmask ok = TRC_FCMP(lo, 0x1p-40f, F_OGE) & TRC_FCMP(hi, 0x1p40f, F_OLT);
-  if ((need & ~ok) == 0ull) {
+  if (__builtin_expect((need & ~ok) == 0ull, 1)) {
     const float rx0 = __builtin_amdgcn_rcpf(d.x), ry0 = __builtin_amdgcn_rcpf(d.y), rz0 = __builtin_amdgcn_rcpf(d.z);
     const float rx = __builtin_fmaf(__builtin_fmaf(-d.x, rx0, 1.0f), rx0, rx0);
     const float ry = __builtin_fmaf(__builtin_fmaf(-d.y, ry0, 1.0f), ry0, ry0);
