@@ -209,7 +209,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
   const uint32_t first = ex.tri_first, count = ex.tri_count;
   float best = FLT_MAX;
   bn = splat3(0.0f);
-  if (mask == 0ull || count == 0u) return best;
+  if (__builtin_expect(mask == 0ull || count == 0u, 0)) return best;
   if (lane_of(mask)) tri_tests += count;
   const unsigned lane = lane_id();
   const unsigned G = count < 64u ? count : 64u;                  // triangles side by side in one pass
@@ -225,7 +225,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
   const unsigned n_pass = __popcll(round);
   // cost model (VALU instructions per wave): pair enumeration ~ ceil(n_pass / R) * n_chunks * 110,
   // ray-per-lane ~ count * 95
-  if (((n_pass + R - 1u) / R) * n_chunks * 5u <= count * 4u) {
+  if (__builtin_expect(((n_pass + R - 1u) / R) * n_chunks * 5u <= count * 4u, 1)) {
     MeshSlot* __restrict__ slots = s_slots + (threadIdx.x >> 6) * TRC_MESH_SLOTS;
     const unsigned rank = __popcll(round & ((1ull << lane) - 1ull));      // < n_pass <= TRC_MESH_SLOTS
     const unsigned long long KEY_NONE = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // t = FLT_MAX
@@ -318,7 +318,7 @@ __device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const Dev
 template <bool SPHERE>
 __device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h,
                                      lmask cand, float t, f3 p, uint32_t k) {
-  if ((cand & h.any) != 0ull) flush_held<SPHERE>(c, ray, xg, h);
+  if (__builtin_expect((cand & h.any) != 0ull, 0)) flush_held<SPHERE>(c, ray, xg, h);
   if (lane_of(cand)) { h.t = t; h.p = p; h.k = k; }
   h.any |= cand;
 }

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
       // one up. Generating only for the lanes that happen to be idle ran this code at ~27 % lane use.
       while (ring_count < n_need && !exhausted) {
         const QueueArgs* ka = kernarg_queue();
-        if (pool_next == pool_end) {
+        if (__builtin_expect(pool_next == pool_end, 0)) {
           const uint32_t grab = load_uniform(&ka->grab), total = load_uniform(&ka->total);
           uint32_t base = 0;
           if (lane == 0) base = atomicAdd(load_uniform(&ka->next_task), grab);
