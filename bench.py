@@ -144,11 +144,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # TRC_BENCH_REHEARSAL=1: every rank on cuda:0 and gloo instead of RCCL (which refuses two ranks on one device):
+    # a check of the N > 1 control flow on a one-GPU box, flagged in the output line; not a measurement.
+    rehearsal = os.environ.get("TRC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # scene + camera through the product's own host API (no oracle here)
     scene = ta.Scene(0)
@@ -170,7 +178,13 @@ def main():
         # rank r renders iterations r+1, r+1+world, ...  (ITERS of them)
         tr.pathtrace(cam, SEED, rank + 1, ITERS, iter_stride=world)
         if world > 1:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+            if rehearsal:                    # gloo: through the host
+                host = film.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    film.copy_(host)
+            else:
+                dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0:
                 tr.tonemap(ITERS * world)
 
@@ -209,10 +223,11 @@ def main():
                           "ok": bool(abs(mean_all - mean_own) <= 0.01 * mean_own)}
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if rehearsal else dev
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        seg = torch.tensor([cnt["live_segments"], cnt["paths"]], dtype=torch.float64, device=dev)
+        seg = torch.tensor([cnt["live_segments"], cnt["paths"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         total_segments, total_paths = float(seg[0].item()), float(seg[1].item())
     else:
@@ -294,6 +309,8 @@ def main():
                 out["roofline"]["valu_issue_utilisation"] = round(insts_per_simd * VALU_ISSUE_CYCLES / cycles, 4)
         if film_check is not None:
             out["film_check"] = film_check
+        if rehearsal:
+            out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
