@@ -301,24 +301,34 @@ __device__ __forceinline__ void consider(Closest& c, const Ray& ray, float t, ui
 // group with the held object's matrix gathered per lane. If any lane meets a second candidate
 // while holding one, the wave flushes first -- every candidate still goes through consider() in
 // object order, so the result is the one the plain loop produces.
-struct Held { lmask any; float t; f3 p; uint32_t k; };   // any: the lanes holding a candidate (wave mask)
+// Meshes join the spheres' group: a mesh hit is held like a sphere's (with its un-normalised object-space normal
+// `n` in place of normalize(p)), and the group is flushed after the last mesh -- the world-space half of the
+// spheres and of the meshes then runs once per trip instead of once per sphere group and once per mesh.
+struct Held { lmask any; float t; f3 p; uint32_t k; f3 n; };   // any: the lanes holding a candidate (wave mask)
 
+// `mesh_first` (SPHERE only): held object numbers from here on are meshes (they follow the spheres and the cubes).
 template <bool SPHERE>
-__device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h) {
+__device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h,
+                                           uint32_t mesh_first = 0xFFFFFFFFu) {
   if (h.any == 0ull) return;
   if (lane_of(h.any)) {
     const DevXform& x = xg[h.k];                                // per-lane gather (a handful of distinct records)
     const Affine m = x.m;
     f3 wn = x.nor_y;                                            // planes: object +y (Ray.inl:156, :62)
-    if (SPHERE) wn = normalize_dev(xform_dir(m, normalize_dev(h.p, h.any)), h.any);   // Ray.inl:116, :62
+    if (SPHERE) {
+      const lmask is_mesh = TRC_UCMP(h.k, mesh_first, I_UGE);
+      const f3 sn = normalize_dev(h.p, h.any & ~is_mesh);       // Ray.inl:116 (a sphere's normal)
+      const f3 on = lane_of(is_mesh) ? h.n : sn;
+      wn = normalize_dev(xform_dir(m, on), h.any);              // Ray.inl:62
+    }
     consider(c, ray, h.t, x.id, m, h.p, wn);
   }
   h.any = 0ull;
 }
 template <bool SPHERE>
 __device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h,
-                                     lmask cand, float t, f3 p, uint32_t k) {
-  if (__builtin_expect((cand & h.any) != 0ull, 0)) flush_held<SPHERE>(c, ray, xg, h);
+                                     lmask cand, float t, f3 p, uint32_t k, uint32_t mesh_first = 0xFFFFFFFFu) {
+  if (__builtin_expect((cand & h.any) != 0ull, 0)) flush_held<SPHERE>(c, ray, xg, h, mesh_first);
   if (lane_of(cand)) { h.t = t; h.p = p; h.k = k; }
   h.any |= cand;
 }
@@ -345,7 +355,7 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, c
 // then Ray.inl:62 normalize(M * (n, 0)) -- both only for a held candidate (flush_held).
 template <int K, uint32_t P>
 __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
-                                        const DevXform* __restrict__ xg, uint32_t first, Held& h) {
+                                        const DevXform* __restrict__ xg, uint32_t first, Held& h, uint32_t mesh_first) {
   Ray r[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) r[k] = to_object_space<P>(ray, load_uniform(&xf[first + k].mi), live);
@@ -360,7 +370,7 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, lmask live, 
     const float q = cr_sqrt(0.25f - m2, hit);
     const float th = lane_of(outside) ? s - q : s + q;
     const f3 p = r[k].pos + r[k].dir * th;
-    hold<true>(c, ray, xg, h, hit & TRC_FCMP(th, 0.0f, F_OGT), th, p, first + k);
+    hold<true>(c, ray, xg, h, hit & TRC_FCMP(th, 0.0f, F_OGT), th, p, first + k, mesh_first);
   }
 }
 
@@ -374,10 +384,10 @@ __device__ __forceinline__ void planes_range(Closest& c, const Ray& ray, lmask l
 }
 template <uint32_t P>
 __device__ __forceinline__ void spheres_range(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
-                                              const DevXform* __restrict__ xg, uint32_t lo, uint32_t hi, Held& h) {
+                                              const DevXform* __restrict__ xg, uint32_t lo, uint32_t hi, Held& h, uint32_t mesh_first) {
   uint32_t i = lo;
-  for (; i + 2 <= hi; i += 2) spheres<2, P>(c, ray, live, xf, xg, i, h);
-  if (i < hi) spheres<1, P>(c, ray, live, xf, xg, i, h);
+  for (; i + 2 <= hi; i += 2) spheres<2, P>(c, ray, live, xf, xg, i, h, mesh_first);
+  if (i < hi) spheres<1, P>(c, ray, live, xf, xg, i, h, mesh_first);
 }
 
 // Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
@@ -405,8 +415,10 @@ __device__ __forceinline__ void cube(Closest& c, const Ray& ray, lmask live, con
 // big mesh whose brute-force pass ran before this kernel (kernels.hip: k_mesh_brute), from that pass's
 // (t, face) key of this ray slot: the winning face is then evaluated once more for its normal
 // (same arithmetic, same t).
+// `xg`, `h`, `k`, `mesh_first`: the spheres' group of held candidates (the mesh is object number k of that table).
 __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g,
-                                     const DevMeshExtra& ex_g, const DevScene& sc, uint32_t slot, uint32_t& tri_tests) {
+                                     const DevMeshExtra& ex_g, const DevScene& sc, uint32_t slot, uint32_t& tri_tests,
+                                     const DevXform* __restrict__ xg, Held& h, uint32_t k, uint32_t mesh_first) {
   const DevXform xf = load_uniform(&xf_g);
   const DevMeshExtra ex = load_uniform(&ex_g);
   const Ray r = to_object_space(ray, xf.mi, live);
@@ -433,10 +445,11 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, lmask live, con
   // forward; the world-space distance test then rejects it because |o + d*FLT_MAX|^2 overflows
   // to inf for any normalised d -> explicit miss here.
   const lmask hit_m = pass_m & TRC_FCMP(tb, FLT_MAX, F_UNE);
-  const bool hit = lane_of(hit_m);
   const f3 p = r.pos + r.dir * tb;
-  const f3 wn = normalize_dev(xform_dir(xf.m, bn), hit_m);    // Ray.inl:62
-  consider(c, ray, hit ? tb : -1.0f, xf.id, xf.m, p, wn);
+  // tb > 0 for every hit (mesh_closest / the key pass keep positive t only): the candidate competes (Ray.inl:72);
+  // its world-space half -- normalize(M * (bn, 0)), M * p, distance -- runs in flush_held()
+  hold<true>(c, ray, xg, h, hit_m, tb, p, k, mesh_first);
+  if (lane_of(hit_m)) h.n = bn;
 }
 
 // Wave-convergent (see the header comment).
@@ -450,7 +463,7 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const
   const DevXform* __restrict__ xf = sc.xf;
   const DevXform* __restrict__ xg = gather;
   uint32_t i = 0;
-  Held h; h.any = 0ull; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u;
+  Held h; h.any = 0ull; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u; h.n = splat3(0.0f);
   // Within a type the objects are sorted by the zero pattern of their m_matrixi (scene.h): one straight-line
   // loop body per pattern. A wavefront with a ray that fails the vector-side condition of sparse_xform.h takes
   // every object through the full product.
@@ -466,9 +479,9 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const
   flush_held<false>(c, ray, xg, h);
   xf += sc.n_plane; xg += sc.n_plane;
   TRC_MARK("spheres");
-  spheres_range<XP_FULL>(c, ray, live, xf, xg, 0u, sparse ? sc.sphere_full : sc.n_sphere, h);
-  if (sparse) spheres_range<XP_DIAG>(c, ray, live, xf, xg, sc.sphere_full, sc.n_sphere, h);
-  flush_held<true>(c, ray, xg, h);
+  const uint32_t mesh_first = sc.n_sphere + sc.n_cube;          // numbering of the spheres' group: [spheres | cubes | meshes]
+  spheres_range<XP_FULL>(c, ray, live, xf, xg, 0u, sparse ? sc.sphere_full : sc.n_sphere, h, mesh_first);
+  if (sparse) spheres_range<XP_DIAG>(c, ray, live, xf, xg, sc.sphere_full, sc.n_sphere, h, mesh_first);
   xf += sc.n_sphere;
   TRC_MARK("cubes");
   const uint32_t cube_full = sparse ? sc.cube_full : sc.n_cube;
@@ -476,7 +489,8 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const
   for (; i < sc.n_cube; ++i) cube<XP_DIAG>(c, ray, live, xf[i], sc.cubes[i]);
   xf += sc.n_cube;
   TRC_MARK("meshes");
-  for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc, slot, tri_tests);
+  for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc, slot, tri_tests, xg, h, mesh_first + i, mesh_first);
+  flush_held<true>(c, ray, xg, h, mesh_first);                   // spheres and meshes
   TRC_MARK("closest_done");
   Hit out; out.t = c.t; out.id = c.id; out.pos = c.pos; out.nor = c.nor;
   return out;

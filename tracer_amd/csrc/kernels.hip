@@ -22,6 +22,9 @@ constexpr int kBlock = 256;
 #define TRC_GATHER_MAX 16
 #endif
 constexpr uint32_t kGatherMax = TRC_GATHER_MAX;   // DevXform records k_queue / k_bounce keep in LDS (2 KB)
+// the records that held candidates gather per lane (intersect.h: flush_held): planes, spheres and -- through the
+// spheres' group -- meshes; the table is the whole DevXform array
+__host__ __device__ inline uint32_t gather_records(const DevScene& sc) { return sc.n_plane + sc.n_sphere + sc.n_cube + sc.n_mesh; }
 
 static inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter
   if (rv.first >= rv.n_in) return;                                    // whole block past its region's queue
   __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];              // as in k_queue: table of the held candidates' gathers
   if (LDS_GATHER) {
-    const uint32_t n_dw = (fp.sc.n_plane + fp.sc.n_sphere) * (uint32_t)(sizeof(DevXform) / 4);
+    const uint32_t n_dw = gather_records(fp.sc) * (uint32_t)(sizeof(DevXform) / 4);
     for (uint32_t k = threadIdx.x; k < n_dw; k += kBlock) ((uint32_t*)s_xf)[k] = ((const uint32_t*)fp.sc.xf)[k];
     __syncthreads();
   }
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
   RaySlot* __restrict__ ring = s_ring + (threadIdx.x >> 6) * kRing;
   // The plane / sphere records that held candidates gather per lane (intersect.h: flush_held), copied to LDS once.
   __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];
-  const uint32_t n_gather = fp.sc.n_plane + fp.sc.n_sphere;
+  const uint32_t n_gather = gather_records(fp.sc);
   if (LDS_GATHER) {
     const uint32_t n_dw = n_gather * (uint32_t)(sizeof(DevXform) / 4);
     for (uint32_t i = threadIdx.x; i < n_dw; i += kBlock) ((uint32_t*)s_xf)[i] = ((const uint32_t*)fp.sc.xf)[i];
@@ -783,7 +786,7 @@ void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t
   hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, cur, queue_count, counters);
   for (int d = 0; d < kPathDepth; ++d) {
     if (bmp) launch_big_mesh_passes<1>(fp, n_slots, cur, compact ? queue_count + d * kRegions * kCountStride : nullptr, *bmp, stream);
-    const bool lds = fp.sc.n_plane + fp.sc.n_sphere <= kGatherMax;
+    const bool lds = gather_records(fp.sc) <= kGatherMax;
     if (compact) {
       hipLaunchKernelGGL((lds ? k_bounce<true, true> : k_bounce<true, false>), grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, next,
                          queue_count + d * kRegions * kCountStride, queue_count + (d + 1) * kRegions * kCountStride, stage, counters);
@@ -811,7 +814,7 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
   unsigned blocks = (unsigned)((paths + kBlock - 1) / kBlock);
   resident_blocks = resident_blocks / 4u * TRC_QUEUE_WAVES;     // CUs x waves per SIMD (a block = 1 wave per SIMD)
   if (blocks > resident_blocks) blocks = resident_blocks;
-  const bool lds_gather = fp.sc.n_plane + fp.sc.n_sphere <= kGatherMax;
+  const bool lds_gather = gather_records(fp.sc) <= kGatherMax;
   // a small call (an interactive frame: one iteration) is spread over all resident wavefronts: about four
   // reservations per wavefront, 64 .. kGrab task ids each
   uint32_t grab = (uint32_t)(paths / ((size_t)blocks * 4u * 4u)) / 64u * 64u;
