@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
 }
 
 template <bool COMPACT, bool LDS_GATHER>
-__global__ __launch_bounds__(kBlock) void k_bounce(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
+__global__ __launch_bounds__(kBlock, COMPACT ? 6 : 5) void k_bounce(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                   uint32_t n_slots, int depth,
                                                   PathState cur, PathState next,
                                                   const uint32_t* __restrict__ count_in,
