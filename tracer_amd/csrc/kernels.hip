@@ -8,6 +8,7 @@
 // The film sum of a pixel is always iteration 1, 2, 3, ... in that order (raytrace.cu:170),
 // and adding the black (0,0,0) of a missed / depth-capped path is skipped because x + 0 == x.
 #include "kernels.h"
+#include <cstddef>
 #include "intersect.h"
 #include "shade.h"
 #include "rng.h"
@@ -601,6 +602,7 @@ struct QueueArgs {
   uint32_t iter_first, iter_stride, total, grab;   // total = tile pixels x iterations = number of path tasks
   float* stage; uint32_t* next_task; DeviceCounters* counters;
 };
+static_assert(offsetof(QueueArgs, fp) == 0, "kernarg_params() reads the FrameParams at offset 0 of the kernel-argument segment");
 __device__ __forceinline__ const QueueArgs* kernarg_queue() { return reinterpret_cast<const QueueArgs*>(kernarg_params()); }
 
 template <bool LDS_GATHER>   // the scene's plane + sphere records fit s_xf (the launcher picks the instantiation)
