@@ -120,6 +120,12 @@ def test_config5_icosphere_1310720_triangles_1024x1024(ta, oracle_c):
     accel = tr.read_hits()
     for k in ("ids", "ts", "pos", "nor"):
         assert accel[k].tobytes() == hits[k].tobytes(), k
+    # and through the exhaustive loop without its bounding-sphere pre-test: again every pixel
+    tr.set_mesh_accel(2)
+    tr.raytrace1(cam)
+    plain = tr.read_hits()
+    for k in ("ids", "ts", "pos", "nor"):
+        assert plain[k].tobytes() == hits[k].tobytes(), k
     tr.set_mesh_accel(False)
     tr.pathtrace(cam, 2, 1, 1)                       # AUTO -> compacted + brute-force pass
     a = tr.read_film()

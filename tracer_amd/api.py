@@ -184,9 +184,11 @@ class Tracer:
         """Render only image rows [row0, row0 + rows) from now on (rows == 0: the whole image)."""
         self._check(self.L.trc_set_tile(self.ctx, row0, rows))
 
-    def set_mesh_accel(self, on):
-        """Big meshes: False = test every face (the reference's loop, default), True = BVH in front of the same test."""
-        self._check(self.L.trc_set_option(self.ctx, OPT_MESH_ACCEL, int(bool(on))))
+    def set_mesh_accel(self, mode):
+        """Big meshes: False / 0 = every face against every ray that passed the AABB (the reference's loop, default; a
+        bounding-sphere pre-test skips the arithmetic of pairs that cannot hit), True / 1 = BVH in front of the same
+        exact test, 2 = the loop without the pre-test (validation)."""
+        self._check(self.L.trc_set_option(self.ctx, OPT_MESH_ACCEL, int(mode)))
 
     def set_stage_mb(self, mb):
         self._check(self.L.trc_set_option(self.ctx, OPT_STAGE_MB, int(mb)))

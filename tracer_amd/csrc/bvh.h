@@ -20,6 +20,7 @@
 #pragma once
 #include "scene.h"
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <vector>
 
@@ -98,6 +99,48 @@ inline void build_bvh(const DevTri* tris, uint32_t n, std::vector<BvhNode>& node
     todo.push_back({ left + 1, mid, j.hi });
   }
   prm.n_nodes = (uint32_t)nodes.size();
+}
+
+// Bounding spheres for the exhaustive pass (kernels.hip: k_mesh_brute<true>): per face a centre (the centroid,
+// as rounded to float) and, for the whole mesh, r_max = the largest distance from a face's centre to one of its
+// vertices -- so every point of a face lies within r_max of its centre. With the bound above, a (ray, face) pair
+// that the floating-point test accepts has the ray's line within pad(o) / 2 of the face, hence within
+// r_max + pad(o) of the centre; the pass skips the exact test for a pair only when the line's distance from the
+// centre is beyond that, with margins for the rounding of the distance itself (k_mesh_brute).
+// `centres` gets one float4 per face (w = 0); prm as in build_bvh; origin_dist = |centre of the mesh|.
+inline void mesh_bound_spheres(const DevTri* tris, uint32_t n, std::vector<float>& centres, BvhParams& prm,
+                               float& r_max, float& origin_dist) {
+  double lo[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, hi[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
+  double emax = 0.0, rmax = 0.0;
+  centres.assign(4ull * n, 0.0f);
+  for (uint32_t i = 0; i < n; ++i) {
+    const DevTri& t = tris[i];
+    const double v[3][3] = { { t.v0.x, t.v0.y, t.v0.z },
+                             { (double)t.v0.x + t.e1.x, (double)t.v0.y + t.e1.y, (double)t.v0.z + t.e1.z },
+                             { (double)t.v0.x + t.e2.x, (double)t.v0.y + t.e2.y, (double)t.v0.z + t.e2.z } };
+    float c[3];
+    for (int a = 0; a < 3; ++a) {
+      c[a] = (float)((v[0][a] + v[1][a] + v[2][a]) / 3.0);
+      centres[4ull * i + a] = c[a];
+      for (int k = 0; k < 3; ++k) { lo[a] = std::min(lo[a], v[k][a]); hi[a] = std::max(hi[a], v[k][a]); }
+    }
+    for (int k = 0; k < 3; ++k) {
+      const double dx = v[k][0] - c[0], dy = v[k][1] - c[1], dz = v[k][2] - c[2];
+      rmax = std::max(rmax, std::sqrt(dx * dx + dy * dy + dz * dz));
+      const int k2 = (k + 1) % 3;
+      const double ex = v[k][0] - v[k2][0], ey = v[k][1] - v[k2][1], ez = v[k][2] - v[k2][2];
+      emax = std::max(emax, std::sqrt(ex * ex + ey * ey + ez * ez));
+    }
+  }
+  if (n == 0) { for (int a = 0; a < 3; ++a) { lo[a] = 0.0; hi[a] = 0.0; } }
+  const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
+  const double hx = 0.5 * (hi[0] - lo[0]), hy = 0.5 * (hi[1] - lo[1]), hz = 0.5 * (hi[2] - lo[2]);
+  prm.centre = mk3((float)cx, (float)cy, (float)cz);
+  prm.radius = (float)(std::sqrt(hx * hx + hy * hy + hz * hz) * 1.00001 + 1e-6 * (std::fabs(cx) + std::fabs(cy) + std::fabs(cz)));
+  prm.max_edge = (float)(emax * 1.00001);
+  prm.n_nodes = 0;
+  r_max = (float)(rmax * 1.00001);
+  origin_dist = (float)(std::sqrt(cx * cx + cy * cy + cz * cz) * 1.00001);
 }
 
 } // namespace trc

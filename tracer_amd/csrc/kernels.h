@@ -64,7 +64,12 @@ constexpr uint32_t kCountStride = 64;
 constexpr uint32_t kRegionSlack = kRegions * 256;   // slots beyond ntile * n_iters that the region layout may address
 
 // ---- big meshes (scene.h: kBigMeshTris): brute-force pass in front of a closest-hit kernel ------
-struct BigMesh { uint32_t mesh_index, hot_first, tri_first, tri_count; };   // host-side list, in big_slot order
+struct BigMesh {                    // host-side list, in big_slot order
+  uint32_t mesh_index, hot_first, tri_first, tri_count;
+  // bounding spheres of the faces (bvh.h: mesh_bound_spheres) for the pre-test of k_mesh_brute<true>;
+  // use_bound: the faces are small against the mesh (r_max <= radius / 4), so the pre-test rejects nearly every pair
+  BvhParams prm; float r_max, origin_dist; uint32_t use_bound;
+};
 // Dense queue of the rays that passed one big mesh's AABB, in that mesh's object space.
 struct MeshRayQueue {
   uint32_t* count;                 // rays queued (device counter)
@@ -79,6 +84,7 @@ struct DevBvh { const BvhNode* nodes; const uint32_t* faces; BvhParams prm; };  
 struct BigMeshPass {
   const BigMesh* big; uint32_t n_big;
   const DevBvh* bvh;               // per big mesh, or null: exhaustive loop (the reference's behaviour)
+  bool plain;                      // exhaustive loop without the bounding-sphere pre-test (TRC_OPT_MESH_ACCEL = 2)
   MeshRayQueue q;
   unsigned long long* keys;
   unsigned grid_blocks;

@@ -266,11 +266,22 @@ constexpr int kRaysPerLane = 2;    // rays a lane of k_mesh_brute carries: every
                                    // (48 B x 64 lanes through the LDS return path) then feeds two tests
 constexpr uint32_t kBruteRays = kBlock * kRaysPerLane;   // rays per work item
 
+// BOUND: a bounding-sphere pre-test in front of all that (meshes whose faces are small against the mesh, BigMesh::
+// use_bound). The LDS tile then holds one float4 per face -- the centre of its bounding sphere -- and a pair goes
+// on to the arithmetic above (its HotTri record read from memory) only if the ray's line passes within
+//   thr = (r_max + pad(o)) * 1.00001 + 1e-6 * (reach + |mesh centre|)
+// of the centre: r_max + pad(o) is as far as the line of a pair that the floating-point test accepts can be
+// (bvh.h: mesh_bound_spheres), and the second term covers the rounding of |(c - o) x d| itself (at most
+// 7 * 2^-24 * (reach + |mesh centre|): three roundings per component of the cross product on operands no larger
+// than |c - o| <= reach, plus the rounding of c - o on coordinates no larger than reach + |mesh centre|).
+// 18 instead of 26 VALU instructions per pair and one LDS read per face instead of three.
+template <bool BOUND>
 __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const HotTri* __restrict__ hot,
                                                       const DevTri* __restrict__ cold, uint32_t tri_count, uint32_t n_tiles,
                                                       uint32_t tiles_per_seg, uint32_t n_segs,
-                                                      unsigned long long* __restrict__ keys) {
-  __shared__ float4 s_tile[kMeshTile * 3];
+                                                      unsigned long long* __restrict__ keys,
+                                                      const float4* __restrict__ bnd, BvhParams prm, float r_max, float origin_dist) {
+  __shared__ float4 s_tile[kMeshTile * (BOUND ? 1 : 3)];
   const uint32_t nq = *q.count;
   const uint32_t n_rb = (nq + kBruteRays - 1) / kBruteRays;
   const uint32_t n_items = n_rb * n_segs;
@@ -289,21 +300,42 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
       o[r] = splat3(0.0f); d[r] = splat3(0.0f); slot[r] = 0; best[r] = kKeyNone;
       if (valid[r]) { slot[r] = q.slot[j]; o[r] = mk3(q.ox[j], q.oy[j], q.oz[j]); d[r] = mk3(q.dx[j], q.dy[j], q.dz[j]); }
     }
+    float thr2[kRaysPerLane];        // BOUND: squared pre-test distance of this lane's rays; -1 = no ray, every pair certain
+#pragma unroll
+    for (int r = 0; r < kRaysPerLane; ++r) {
+      thr2[r] = -1.0f;
+      if (BOUND && valid[r]) {
+        const f3 oc = o[r] - prm.centre;
+        const float reach = sqrtf(dot(oc, oc)) + prm.radius;
+        const float pad = kPadScale * prm.max_edge * prm.max_edge * (reach + prm.max_edge);
+        const float thr = (r_max + pad) * 1.00001f + 1e-6f * (reach + origin_dist);
+        thr2[r] = thr * thr;
+      }
+    }
     const uint32_t tile0 = seg * tiles_per_seg;
     const uint32_t tile1 = (tile0 + tiles_per_seg < n_tiles) ? tile0 + tiles_per_seg : n_tiles;
     const float4* __restrict__ src = reinterpret_cast<const float4*>(hot);
     // this lane's record of the first tile (records are padded to whole tiles at upload)
-    float4 r0 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 0];
-    float4 r1 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 1];
-    float4 r2 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 2];
+    float4 r0, r1, r2;
+    if (BOUND) {
+      r0 = bnd[(size_t)tile0 * kMeshTile + threadIdx.x]; r1 = r0; r2 = r0;
+    } else {
+      r0 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 0];
+      r1 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 1];
+      r2 = src[((size_t)tile0 * kMeshTile + threadIdx.x) * 3 + 2];
+    }
     for (uint32_t tile = tile0; tile < tile1; ++tile) {
       __syncthreads();                                     // everyone is done with the previous tile
-      s_tile[threadIdx.x * 3 + 0] = r0; s_tile[threadIdx.x * 3 + 1] = r1; s_tile[threadIdx.x * 3 + 2] = r2;
+      if (BOUND) s_tile[threadIdx.x] = r0;
+      else { s_tile[threadIdx.x * 3 + 0] = r0; s_tile[threadIdx.x * 3 + 1] = r1; s_tile[threadIdx.x * 3 + 2] = r2; }
       __syncthreads();
       if (tile + 1 < tile1) {                              // next tile's record is in flight during the tests
-        r0 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 0];
-        r1 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 1];
-        r2 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 2];
+        if (BOUND) r0 = bnd[(size_t)(tile + 1) * kMeshTile + threadIdx.x];
+        else {
+          r0 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 0];
+          r1 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 1];
+          r2 = src[((size_t)(tile + 1) * kMeshTile + threadIdx.x) * 3 + 2];
+        }
       }
       if (__ballot(valid[0]) == 0ull) continue;            // a wavefront past the end of the queue only helps copying
       // one triangle record against this lane's rays
@@ -359,6 +391,28 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
           }
         }
       };
+      if (BOUND) {
+        // the pre-test; !(n > thr2) as "unordered or <=", so that a NaN keeps the pair
+        auto pre = [&](const float4& c, uint32_t k) {
+          lmask open = 0ull;
+#pragma unroll
+          for (int r = 0; r < kRaysPerLane; ++r) {
+            const f3 w = cross(mk3(c.x, c.y, c.z) - o[r], d[r]);
+            open |= TRC_FCMP(dot(w, w), thr2[r], 13 /* FCMP_ULE */);
+          }
+          if (__builtin_expect(open == 0ull, 1)) return;
+          const size_t rec = ((size_t)tile * kMeshTile + k) * 3;           // wave-uniform address
+          test(src[rec], src[rec + 1], src[rec + 2], k);
+        };
+        float4 c0 = s_tile[0], c1;
+        for (uint32_t k = 0; k < kMeshTile; k += 2) {
+          c1 = s_tile[k + 1];
+          pre(c0, k);
+          if (k + 2 < kMeshTile) c0 = s_tile[k + 2];
+          pre(c1, k + 1);
+        }
+        continue;
+      }
       // two register sets take turns, so the next record's LDS read is in flight during a test
       float4 a0 = s_tile[0], b0 = s_tile[1], c0 = s_tile[2], a1, b1, c1;
       for (uint32_t k = 0; k < kMeshTile; k += 2) {
@@ -764,9 +818,11 @@ static void launch_big_mesh_passes(const FrameParams& fp, uint32_t n_slots, Path
                          bmp.keys + (size_t)b * fp.sc.key_stride);
       continue;
     }
-    hipLaunchKernelGGL(k_mesh_brute, dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
+    const bool bound = m.use_bound && !bmp.plain;
+    hipLaunchKernelGGL((bound ? k_mesh_brute<true> : k_mesh_brute<false>), dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
                        bmp.q, fp.sc.hot + m.hot_first, fp.sc.tris + m.tri_first, m.tri_count, n_tiles,
-                       tiles_per_seg, n_segs, bmp.keys + (size_t)b * fp.sc.key_stride);
+                       tiles_per_seg, n_segs, bmp.keys + (size_t)b * fp.sc.key_stride,
+                       reinterpret_cast<const float4*>(fp.sc.tri_bound) + m.hot_first, m.prm, m.r_max, m.origin_dist);
   }
 }
 

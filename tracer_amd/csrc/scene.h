@@ -102,6 +102,7 @@ struct DevScene {
   const DevMaterial*  mats;        // nobj, indexed by ORIGINAL object index
   const DevTri*       tris;        // triangle stream
   const HotTri*       hot;         // big meshes only: the 36 bytes per triangle every test reads
+  const float*        tri_bound;   // big meshes only, indexed like `hot`: centre of the face's bounding sphere (x, y, z, 0)
   uint32_t n_plane, n_sphere, n_cube, n_mesh;
   // Set per launch by the host: closest (t, face) per ray slot per big mesh as found by the
   // brute-force pass that ran before this kernel, keys[big_slot * key_stride + slot]; null in the

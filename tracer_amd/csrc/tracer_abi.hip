@@ -125,7 +125,7 @@ void free_bvh(trc_ctx* c) {
 // Build (host, median split) and upload the hierarchy of every big mesh; meshes live in object space, so
 // trc_update_object leaves them valid and only trc_upload_scene discards them.
 int ensure_bvh(trc_ctx* c) {
-  if (!c->mesh_accel || c->bvh.size() == c->big.size()) return TRC_OK;
+  if (c->mesh_accel != 1 || c->bvh.size() == c->big.size()) return TRC_OK;
   free_bvh(c);
   for (const BigMesh& m : c->big) {
     std::vector<BvhNode> nodes; std::vector<uint32_t> faces; BvhParams prm;
@@ -173,7 +173,8 @@ int ensure_big_mesh_buffers(trc_ctx* c, size_t slots) {
 BigMeshPass big_mesh_pass(const trc_ctx* c) {
   BigMeshPass b;
   b.big = c->big.data(); b.n_big = (uint32_t)c->big.size();
-  b.bvh = (c->mesh_accel && c->bvh.size() == c->big.size() && !c->bvh.empty()) ? c->bvh.data() : nullptr;
+  b.bvh = (c->mesh_accel == 1 && c->bvh.size() == c->big.size() && !c->bvh.empty()) ? c->bvh.data() : nullptr;
+  b.plain = c->mesh_accel == 2;
   b.q = c->mesh_queue; b.keys = c->mesh_keys; b.grid_blocks = c->brute_blocks;
   return b;
 }
@@ -270,6 +271,7 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
                   std::vector<unsigned char>& blob, std::vector<BigMesh>& big) {
   std::vector<DevXform> xf; std::vector<DevCubeExtra> cubes; std::vector<DevMeshExtra> meshes;
   std::vector<HotTri> hot;
+  std::vector<float> bound;          // 4 floats per `hot` record
   big.clear();
   std::vector<DevMaterial> mats(objs.size());
   const int order[4] = { REF_PLANE, REF_SPHERE, REF_CUBE, REF_MESH };
@@ -297,6 +299,10 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
           e.big_slot = (uint32_t)big.size(); e.hot_first = (uint32_t)hot.size();
           BigMesh b; b.mesh_index = (uint32_t)meshes.size(); b.hot_first = e.hot_first;
           b.tri_first = o.tri_first; b.tri_count = o.tri_count;
+          std::vector<float> centres;
+          mesh_bound_spheres(tris.data() + o.tri_first, o.tri_count, centres, b.prm, b.r_max, b.origin_dist);
+          b.use_bound = b.r_max <= 0.25f * b.prm.radius;
+          bound.insert(bound.end(), centres.begin(), centres.end());
           big.push_back(b);
           for (uint32_t t = 0; t < o.tri_count; ++t) {
             const DevTri& src = tris[o.tri_first + t];
@@ -306,6 +312,7 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
           }
           HotTri zero; memset(&zero, 0, sizeof zero);
           while (hot.size() % kMeshTile) hot.push_back(zero);
+          bound.resize(4 * hot.size(), 0.0f);
         }
         meshes.push_back(e);
       }
@@ -328,6 +335,7 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
   append(mats.data(), mats.size() * sizeof(DevMaterial));
   append(tris.data(), tris.size() * sizeof(DevTri));
   append(hot.data(), hot.size() * sizeof(HotTri));
+  append(bound.data(), bound.size() * sizeof(float));
   blob.resize(blob.size() + 256);                              // slack: empty sections still get valid addresses
   return blob.size();
 }
@@ -351,6 +359,11 @@ DevScene scene_pointers(const std::vector<DevObject>& objs, const std::vector<De
   sc.mats = (const DevMaterial*)p;    p += up(objs.size() * sizeof(DevMaterial));
   sc.tris = (const DevTri*)p;         p += up(tris.size() * sizeof(DevTri));
   sc.hot = (const HotTri*)p;
+  size_t n_hot = 0;                   // as pack_scene lays them out: every big mesh padded to whole tiles
+  for (const DevObject& o : objs)
+    if (o.mesh_type == REF_MESH && o.tri_count >= kBigMeshTris) n_hot += (o.tri_count + kMeshTile - 1) / kMeshTile * kMeshTile;
+  p += up(n_hot * sizeof(HotTri));
+  sc.tri_bound = (const float*)p;
   return sc;
 }
 
@@ -446,7 +459,7 @@ int trc_set_option(trc_ctx* c, int option, int value) {
     case TRC_OPT_RECORD_HITS:
       c->record_hits = value ? 1 : 0; return TRC_OK;
     case TRC_OPT_MESH_ACCEL:
-      if (value != 0 && value != 1) return fail(TRC_ERR_INVALID, "bad mesh acceleration mode");
+      if (value < 0 || value > 2) return fail(TRC_ERR_INVALID, "bad mesh acceleration mode");
       c->mesh_accel = value; return TRC_OK;
     case TRC_OPT_STAGE_MB:
       if (value < 1) return fail(TRC_ERR_INVALID, "bad staging budget");
