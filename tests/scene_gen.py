@@ -82,3 +82,60 @@ def aligned_scene(path, lens=0.7):
     with open(path, "w") as f:
         f.write("\n".join(L) + "\n")
     return path
+
+
+def icosphere_obj(path, level=3, offset=(0.0, 0.0, 0.0), stretch=(1.0, 1.0, 1.0), radius=1.0, spike=1.0):
+    """A subdivided icosahedron written in the loader's .obj dialect (v / vn / f a//b), its vertices stretched per
+    axis and then moved by `offset` in OBJECT space -- a big mesh that does not sit at its own origin."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    v = [np.array(p, float) / np.linalg.norm(p) for p in v]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(level):
+        mid = {}
+
+        def midpoint(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p)); mid[key] = len(v) - 1
+            return mid[key]
+        nf = []
+        for a, b, c in f:
+            ab, bc, ca = midpoint(a, b), midpoint(b, c), midpoint(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    s, o = np.array(stretch, float), np.array(offset, float)
+    v[0] = v[0] * spike                      # spike > 1: a few faces far larger than the rest
+    with open(path, "w") as out:
+        for p in v:
+            q = p * radius * s + o
+            out.write("v %.9g %.9g %.9g\n" % tuple(q))
+        for p in v:
+            n = p / s; n = n / np.linalg.norm(n)
+            out.write("vn %.9g %.9g %.9g\n" % tuple(n))
+        for a, b, c in f:
+            out.write("f %d//%d %d//%d %d//%d\n" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1))
+    return path, len(f)
+
+
+def offset_mesh_scene(path, obj_path, offset, scale=2.0, lens=0.5):
+    """Cornell walls + light + one big mesh whose object-space geometry sits at `offset`; the object is moved back
+    so that it hangs in the middle of the box."""
+    L = ["camera fov 30 zoom -13 focal 13 lens %g" % lens, "mesh wall plane", "mesh box cube", f"mesh blob obj {obj_path}"]
+    walls = [(None, (0, -5, 0), (1, 1, 1)), ((180, 1, 0, 0), (0, 5, 0), (1, 1, 1)), ((90, 1, 0, 0), (0, 0, -5), (1, 1, 1)),
+             ((90, 0, 0, 1), (5, 0, 0), (0.5, 0.5, 1)), ((-90, 0, 0, 1), (-5, 0, 0), (1, 0.5, 0.5))]
+    for rot, at, col in walls:
+        L.append("object wall")
+        if rot:
+            L.append("  rotate %g %g %g %g" % rot)
+        L += ["  scale 10 10 10", "  translate %g %g %g" % at, "  color %g %g %g" % col]
+    L += ["object box", "  scale 5 0.5 5", "  translate 0 5 0", "  color 1 1 1", "  emit 2"]
+    # Object::scale multiplies from the right (object space), Object::rotate from the left (about the world origin)
+    L += ["object blob", "  scale %g" % scale, "  translate %.9g %.9g %.9g" % tuple(-scale * np.array(offset, float)), "  rotate 20 0.2 1 0.1",
+          "  translate 0.3 -1 0.5", "  color 0.9 0.8 0.3"]
+    with open(path, "w") as f:
+        f.write("\n".join(L) + "\n")
+    return path
