@@ -1,5 +1,5 @@
 """configs[4]: Cornell walls + one tessellated icosphere MESH, brute-force closest hit.
-    python3 tools/mesh_bench.py [level=8] [w=1024] [h=1024] [mode2_iters=1] [pipeline=-1 (library default)] [accel=0]
+    python3 tools/mesh_bench.py [level=8] [w=1024] [h=1024] [mode2_iters=1] [pipeline=-1 (library default)] [accel=0|1|2]
 Prints mode-1 and mode-2 kernel time and ray-triangle tests/s."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,8 +22,9 @@ t0 = time.time()
 tr.upload_scene(sc.objects_ptr, sc.size)
 print(f"scene uploaded in {time.time()-t0:.2f} s", flush=True)
 tr.set_record_hits(True)
-tr.set_mesh_accel(bool(accel))
-print("big meshes:", "BVH (TRC_OPT_MESH_ACCEL = 1)" if accel else "every face (the reference's loop)", flush=True)
+tr.set_mesh_accel(accel)
+print("big meshes:", ["every face (the reference's loop; bounding-sphere pre-test)", "BVH (TRC_OPT_MESH_ACCEL = 1)",
+                      "every face, no pre-test (TRC_OPT_MESH_ACCEL = 2)"][accel], flush=True)
 for rep in range(2):
     tr.reset_counters()
     tr.raytrace1(cam)
