@@ -74,7 +74,7 @@ typedef enum trc_rng_mode { TRC_RNG_REFERENCE = 0, TRC_RNG_DECORRELATED = 1 } tr
  *                       work queue, so lanes never idle on short paths or cheap pixels; the
  *                       samples pass through a staging buffer in HBM and are summed per pixel
  *                       in iteration order by a second kernel;
- *  TRC_PIPE_AUTO       TRC_PIPE_QUEUE (TRC_PIPE_FUSED for calls of fewer than 1.5 M paths, e.g. one
+ *  TRC_PIPE_AUTO       TRC_PIPE_QUEUE (TRC_PIPE_FUSED for calls of fewer than 2.4 M paths, e.g. one
  *                       interactive frame), except for a scene with a MESH of 1024 triangles or more:
  *                       then TRC_PIPE_COMPACTED, where the brute-force loop over that mesh's faces
  *                       (Ray.inl:172-177) runs as a pass of its own before every bounce, over a

@@ -540,10 +540,11 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
   const uint32_t last_iter = iter_first + (n_iters - 1) * iter_stride;
   // TRC_PIPE_AUTO: the work queue; the compacted pipeline when a big mesh makes the per-bounce brute-force pass
   // worth a launch; the fused kernel for a small call (an interactive frame: one iteration of 512x512 takes
-  // 0.07 ms fused, 0.16 ms through the queue; the queue wins from about 1.5 M paths on)
+  // 0.07 ms fused, 0.16 ms through the queue; the queue wins from about 2.4 M paths on:
+  // 8 iterations of 512x512 take 0.48 ms fused and 0.51 ms through the queue, 12 take 0.72 and 0.52)
   const int pipeline = c->pipeline != TRC_PIPE_AUTO ? c->pipeline
                      : !c->big.empty() ? TRC_PIPE_COMPACTED
-                     : (uint64_t)fp.ntile * n_iters <= 1500000ull ? TRC_PIPE_FUSED : TRC_PIPE_QUEUE;
+                     : (uint64_t)fp.ntile * n_iters <= 2400000ull ? TRC_PIPE_FUSED : TRC_PIPE_QUEUE;
   BigMeshPass bmp = {};
   const BigMeshPass* pass = nullptr;
   const bool wave = pipeline == TRC_PIPE_WAVEFRONT || pipeline == TRC_PIPE_COMPACTED;
