@@ -639,7 +639,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_fused(FrameParams fp, uint32_t it
 // light stores its radiance -- every other path a zero -- into a staging buffer stage[iteration][pixel]
 // (12 B per path; 0.94 GB for 512x512x300, nothing against 288 GB of HBM) and
 // k_accumulate adds the staged samples per pixel in iteration order afterwards.
-constexpr uint32_t kGrab = 512;   // task ids a wavefront reserves at a time (fewer when the whole call is small: launch_queue)
+#ifndef TRC_GRAB
+#define TRC_GRAB 256          // measured on the headline workload: 128 -> 8.10 ms, 256 -> 8.08, 512 -> 8.16, 1024 -> 8.35 (tail of the last grabs)
+#endif
+constexpr uint32_t kGrab = TRC_GRAB;   // task ids a wavefront reserves at a time (fewer when the whole call is small: launch_queue)
 // One camera ray parked in a wavefront's LDS ring (k_queue).
 struct alignas(16) RaySlot { float px, py, pz, dx; float dy, dz; uint32_t pixel, itk; };
 static_assert(sizeof(RaySlot) == 32, "RaySlot");
