@@ -11,7 +11,7 @@
 // block citing the lines it follows:
 //   * src/raytrace.cu kernel bodies (needs nvcc/cuda_runtime.h/curand.h)
 //   * src/Renderer.cpp:156-171 camera basis (file needs GL + CUDA-GL interop)
-//   * src/Mesh.h newGeometry/loadObj (MSVC-only sscanf_s at Mesh.h:39)
+// src/Mesh.h (newGeometry, loadObj) is compiled verbatim behind a one-line sscanf_s macro.
 // The hard-coded scene (src/main.cpp:274-396) is NOT restated: the Makefile extracts that
 // line range into a temporary include directory at build time and it is compiled verbatim.
 //
@@ -38,23 +38,59 @@
 #include "icosphere.h"
 
 // ---------------------------------------------------------------------------------------
-// Mesh.h restated (host-only loader; Mesh.h:6-18 newGeometry, Mesh.h:20-126 loadObj)
+// src/Mesh.h (newGeometry :6-18, loadObj :20-126) compiled VERBATIM. Its one MSVC-ism is
+// sscanf_s at Mesh.h:39, whose result (`str`) is never used; the macro maps it onto sscanf
+// (SURVEY.md 8c). loadObj opens its argument relative to the working directory and prints a
+// "Loaded ..." line on stdout: LoadScope below changes into the directory that holds
+// data/icosahedron.obj and silences stdout for the duration of the call, nothing else.
 // ---------------------------------------------------------------------------------------
-static std::string g_data_dir; // where "data/icosahedron.obj" is looked up
+#include <unistd.h>
+#include <fcntl.h>
+#define sscanf_s(buf, fmt, str, n) sscanf(buf, fmt, str)
+#include "Mesh.h"
+#undef sscanf_s
+
+static std::string g_data_dir; // a directory holding data/icosahedron.obj, or that file itself
+
+namespace {
+  bool readable(const std::string& p) { return access(p.c_str(), R_OK) == 0; }
+
+  struct LoadScope {
+    int cwd_fd, out_fd;
+    bool ok;
+    LoadScope() : cwd_fd(open(".", O_RDONLY)), out_fd(-1), ok(false) {
+      // <dir>/data/icosahedron.obj (the reference checkout) or <dir> == .../data (the repo's own copy)
+      std::string root;
+      if (readable(g_data_dir + "/data/icosahedron.obj")) root = g_data_dir;
+      else if (readable(g_data_dir + "/icosahedron.obj")) {
+        size_t slash = g_data_dir.find_last_not_of('/');
+        std::string trimmed = g_data_dir.substr(0, slash + 1);
+        size_t cut = trimmed.rfind('/');
+        if (cut != std::string::npos && trimmed.substr(cut + 1) == "data") root = trimmed.substr(0, cut);
+      }
+      if (root.empty() || cwd_fd < 0 || chdir(root.c_str()) != 0) {
+        fprintf(stderr, "oracle: no data/icosahedron.obj under '%s'\n", g_data_dir.c_str());
+        return;                                   // Mesh.h:26 would exit(0) the test process
+      }
+      fflush(stdout);
+      out_fd = dup(1);
+      int nul = open("/dev/null", O_WRONLY);
+      if (nul >= 0) { dup2(nul, 1); close(nul); }
+      ok = true;
+    }
+    ~LoadScope() {
+      if (out_fd >= 0) { fflush(stdout); dup2(out_fd, 1); close(out_fd); }
+      if (cwd_fd >= 0) { if (fchdir(cwd_fd) != 0) perror("oracle: fchdir"); close(cwd_fd); }
+    }
+  };
+}
 
 namespace Mesh {
-  Mesh* newGeometry(const MeshType type) {         // Mesh.h:6-18
-    Mesh* mesh = (Mesh*)malloc(sizeof(Mesh));
-    mesh->m_type = type;
-    mesh->m_bmin = glm::vec3(-0.5f);
-    mesh->m_bmax = glm::vec3(0.5f);
-    mesh->m_faces = NULL; mesh->m_norms = NULL; mesh->m_verts = NULL;
-    mesh->m_numFaces = 0; mesh->m_numNorms = 0; mesh->m_numVerts = 0;
-    return mesh;
-  }
-
+  // The "construct Mesh" tail of loadObj (Mesh.h:84-113) for arrays that are already in memory:
+  // used only for the synthetic icosphere of BASELINE.json configs[4] (variant 2 below), which the
+  // reference has no file for. Same AABB rule, FLT_MIN (sic, Mesh.h:104) included.
   static Mesh* fromArrays(const std::vector<glm::vec3>& verts, const std::vector<glm::vec3>& norms,
-                          const std::vector<Face>& faces) {   // Mesh.h:84-113
+                          const std::vector<Face>& faces) {
     Mesh* mesh = (Mesh*)malloc(sizeof(Mesh));
     mesh->m_type = MESH;
     mesh->m_verts = (glm::vec3*)malloc(verts.size()*sizeof(glm::vec3));
@@ -67,51 +103,12 @@ namespace Mesh {
     memcpy(mesh->m_faces, faces.data(), faces.size()*sizeof(Face));
     mesh->m_numFaces = faces.size();
     mesh->m_bmin = glm::vec3(FLT_MAX);
-    mesh->m_bmax = glm::vec3(FLT_MIN);              // sic, Mesh.h:104
+    mesh->m_bmax = glm::vec3(FLT_MIN);
     for (uint i=0; i<mesh->m_numVerts; ++i) {
-      mesh->m_bmin.x = glm::min(mesh->m_bmin.x, mesh->m_verts[i].x);
-      mesh->m_bmin.y = glm::min(mesh->m_bmin.y, mesh->m_verts[i].y);
-      mesh->m_bmin.z = glm::min(mesh->m_bmin.z, mesh->m_verts[i].z);
-      mesh->m_bmax.x = glm::max(mesh->m_bmax.x, mesh->m_verts[i].x);
-      mesh->m_bmax.y = glm::max(mesh->m_bmax.y, mesh->m_verts[i].y);
-      mesh->m_bmax.z = glm::max(mesh->m_bmax.z, mesh->m_verts[i].z);
+      mesh->m_bmin = glm::min(mesh->m_bmin, mesh->m_verts[i]);
+      mesh->m_bmax = glm::max(mesh->m_bmax, mesh->m_verts[i]);
     }
     return mesh;
-  }
-
-  Mesh* loadObj(const std::string filename) {      // Mesh.h:20-126
-    std::string path = g_data_dir.empty() ? filename : g_data_dir + "/" + filename;
-    std::ifstream in(path.c_str());
-    if (!in.good()) {
-      // the repo keeps its own copy of the data file as <dir>/icosahedron.obj
-      size_t slash = filename.rfind('/');
-      std::string base = slash == std::string::npos ? filename : filename.substr(slash+1);
-      path = g_data_dir + "/" + base;
-      in.close(); in.clear(); in.open(path.c_str());
-    }
-    if (!in.good()) { fprintf(stderr, "ERROR: loading obj:(%s)\n", path.c_str()); return NULL; }
-    char buffer[256];
-    float f1,f2,f3;
-    std::vector<glm::vec3> verts, norms;
-    std::vector<Face> faces;
-    while (!in.getline(buffer,255).eof()) {
-      buffer[255] = '\0';
-      if (buffer[0]=='v' && buffer[1]==' ') {
-        if (sscanf(buffer,"v %f %f %f",&f1,&f2,&f3)==3) verts.push_back(glm::vec3(f1,f2,f3));
-      }
-      if (buffer[0]=='v' && buffer[1]=='n' && buffer[2]==' ') {
-        if (sscanf(buffer,"vn %f %f %f",&f1,&f2,&f3)==3) norms.push_back(glm::vec3(f1,f2,f3));
-      }
-      else if (buffer[0]=='f' && buffer[1]==' ') {
-        Face f;
-        int nt = sscanf(buffer,"f %u//%u %u//%u %u//%u",
-          &f.m_v.x,&f.m_n.x,&f.m_v.y,&f.m_n.y,&f.m_v.z,&f.m_n.z);
-        if (nt!=6) { fprintf(stderr, "ERROR: FaceMtl format\n"); return NULL; }
-        f.m_v -= 1; f.m_n -= 1;
-        faces.push_back(f);
-      }
-    }
-    return fromArrays(verts, norms, faces);
   }
 }
 
@@ -147,7 +144,7 @@ void* orc_scene_create(int variant, int param, const char* data_dir) {
   if (variant == 0 || variant == 1) {
     scene.clear();
     camera = ThirdPersonCamera();
-    initScene();
+    { LoadScope in_data_root; if (!in_data_root.ok) { delete s; return NULL; } initScene(); }   // main.cpp:387 loads "data/icosahedron.obj"
     s->objs = scene;
     scene.clear();
     if (s->objs.size() != 9 || s->objs[8].m_mesh == NULL) { delete s; return NULL; }
@@ -157,8 +154,10 @@ void* orc_scene_create(int variant, int param, const char* data_dir) {
     }
   } else if (variant == 2) {                  // BASELINE.json configs[4]: icosphere MESH
     camera = ThirdPersonCamera();
-    wallsAndLight(s->objs);
-    Mesh::Mesh* base = Mesh::loadObj("data/icosahedron.obj");
+    Mesh::Mesh* base = NULL;
+    { LoadScope in_data_root; if (!in_data_root.ok) { delete s; return NULL; }
+      wallsAndLight(s->objs);
+      base = Mesh::loadObj("data/icosahedron.obj"); }
     if (!base) { delete s; return NULL; }
     std::vector<uint32_t> f0(3*base->m_numFaces);
     for (uint i=0;i<base->m_numFaces;++i) for (int k=0;k<3;++k) f0[3*i+k] = base->m_faces[i].m_v[k];

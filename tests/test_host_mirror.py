@@ -120,6 +120,25 @@ def test_camera_frames_equal_reference_fixture(product_lib, golden):
         assert cam.as_array().tobytes() == expect.tobytes(), args
 
 
+def test_product_icosahedron_is_the_closed_form_and_equals_the_fixture(product_lib, tmp_path):
+    """tracer_amd/data/icosahedron.obj is an output of tools/make_icosahedron.py (golden-ratio closed form, six
+    decimals), and it loads to the same vertices, normals, faces and AABB as the fixture tests/golden/icosahedron.obj
+    (the scene input the reference-build fixtures were generated with)."""
+    import subprocess
+    import sys
+    import tracer_amd as ta
+    out = tmp_path / "ico.obj"
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "make_icosahedron.py"), str(out)], check=True,
+                   stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(REPO, "tracer_amd", "data", "icosahedron.obj")).read()
+    sc = ta.Scene(0)
+    a = sc.add_obj(str(out))
+    b = sc.add_obj(os.path.join(REPO, "tests", "golden", "icosahedron.obj"))
+    objs = _flatten_objects(sc.raw_objects(), sc.size)
+    for k in ("counts", "verts", "norms", "faces", "bmin", "bmax"):
+        assert objs[a][k] == objs[b][k] == objs[8][k], k
+
+
 def test_obj_loader_dialects_and_errors(product_lib, tmp_path):
     import tracer_amd as ta
     sc = ta.Scene(0)
