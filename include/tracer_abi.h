@@ -134,6 +134,22 @@ int trc_raytrace1(trc_ctx* ctx, const trc_camera* cam);
  * reference's last accumColorKernel (raytrace.cu:173). seed keys the RNG (rng.h).          */
 int trc_pathtrace(trc_ctx* ctx, const trc_camera* cam, uint64_t seed,
                   uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters);
+/* ---- ray queries (the interactive path's picking, main.cpp:180-208) ------------------------ */
+/* Ray::intersectScene (Ray.inl:66-84) for n caller rays against the uploaded scene -- what main.cpp:202 does on
+ * the CPU for the picking ray. rays6[i] = {pos.xyz, dir.xyz}, the direction used as given (intersectScene does
+ * not normalise it either). Per ray: Hit::m_id (-1 = no hit), m_t (object-space parameter, -1 on a miss), m_pos,
+ * m_nor (zero on a miss). HOST arrays; any output may be NULL; returns after the results have arrived. */
+int trc_intersect_rays(trc_ctx* ctx, const float* rays6, uint32_t n,
+                       int32_t* ids, float* ts, float* pos3, float* nor3);
+/* Same with DEVICE arrays, asynchronous on the context's stream (no copies, no waiting). */
+int trc_intersect_rays_device(trc_ctx* ctx, const void* rays6_d, uint32_t n,
+                              void* ids_d, void* ts_d, void* pos3_d, void* nor3_d);
+/* main.cpp:180-208 in one call: the pixel-corner ray through window position (x, y) of a window_w x window_h
+ * window -- y counted from the TOP as GLUT reports it, uv = (x / window_w, (window_h - y) / window_h), no jitter --
+ * then intersectScene. *id = the clicked object (main.cpp:203-206: valid when >= 0). Outputs may be NULL. */
+int trc_pick(trc_ctx* ctx, const trc_camera* cam, uint32_t window_w, uint32_t window_h, int32_t x, int32_t y,
+             int32_t* id, float* t, float* pos3, float* nor3);
+
 /* Renderer::resetFilm (Renderer.cpp:209-211); also zeroes the film buffer itself so that a
  * rank that never renders iteration 1 starts from zero. */
 int trc_reset_film(trc_ctx* ctx);

@@ -100,6 +100,11 @@ void orc_tonemap(const float* film, unsigned n, float iters, uint32_t* pbo);
 /* ---- unit-level entry points ---------------------------- */
 void  orc_intersect_scene(const void* scene, const float ray6[6], float* t, int* id, float pos[3], float nor[3]);
 void  orc_intersect_object(const void* scene, unsigned obj, const float ray6[6], float* t, float pos[3], float nor[3]);
+/* Picking, main.cpp:180-208: the ray through window position (x, y) as GLUT reports it (y from the top:
+ * uv = (x / window_w, (window_h - y) / window_h), pixel corner, no jitter), then Ray::intersectScene.
+ * `cam` carries the A/B/C basis that main.cpp:187-194 recomputes with the formulas of Renderer.cpp:159-170. */
+void  orc_pick(const void* scene, const orc_camera* cam, int window_w, int window_h, int x, int y,
+               float ray6[6], float* t, int* id, float pos[3], float nor[3]);
 void  orc_bounce(int mat_type, float mat_n, const float rd[3], const float nor[3], const float rnd[3], float out[3]);
 float orc_reflectance(const float inc[3], const float nor[3], float n1, float n2);
 void  orc_rand_vector(float r1, float r2, float out[3]);

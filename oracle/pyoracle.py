@@ -3,6 +3,7 @@
 Loads either CPU checker:
   Oracle("c")   -> oracle/libtracer_oracle.so      (plain-C restatement)
   Oracle("ref") -> oracle/_ref/libtracer_ref.so    (reference .inl + GLM host build)
+  Oracle("ref_pm") -> oracle/_ref/libtracer_ref_pm.so  (the same with portable sin/cos/acos/pow interposed)
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -18,6 +19,8 @@ REF_DIR = "/root/reference"
 LIBS = {
     "c": os.path.join(HERE, "libtracer_oracle.so"),
     "ref": os.path.join(HERE, "_ref", "libtracer_ref.so"),
+    # the same reference sources with sinf/cosf/acosf/powf bound to oracle/pmath.h (oracle/pm_interpose.c)
+    "ref_pm": os.path.join(HERE, "_ref", "libtracer_ref_pm.so"),
 }
 
 
@@ -81,6 +84,7 @@ class Oracle:
         L.orc_tonemap.argtypes = [vp, u32, f32, vp]
         L.orc_intersect_scene.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orc_intersect_object.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.orc_pick.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, vp, vp, vp, vp, vp]
         L.orc_bounce.argtypes = [i32, f32, vp, vp, vp, vp]
         L.orc_reflectance.argtypes = [vp, vp, f32, f32]; L.orc_reflectance.restype = f32
         L.orc_rand_vector.argtypes = [f32, f32, vp]
@@ -106,7 +110,7 @@ class Oracle:
     # -- scenes ----------------------------------------------------------------------
     def scene_create(self, variant=0, param=0, data_dir=None):
         if data_dir is None:
-            data_dir = REF_DIR if (self.kind == "ref" and os.path.isdir(REF_DIR)) else DATA_DIR
+            data_dir = REF_DIR if (self.kind.startswith("ref") and os.path.isdir(REF_DIR)) else DATA_DIR
         s = self.lib.orc_scene_create(variant, param, data_dir.encode())
         if not s:
             raise RuntimeError("orc_scene_create failed")
@@ -201,6 +205,13 @@ class Oracle:
         t = C.c_float(); pos = np.zeros(3, np.float32); nor = np.zeros(3, np.float32)
         self.lib.orc_intersect_object(s, obj, _fp(r), C.addressof(t), _fp(pos), _fp(nor))
         return np.float32(t.value), pos, nor
+
+    def pick(self, s, cam, window_w, window_h, x, y):
+        """main.cpp:180-208: (ray6, t, id, pos, nor) of the picking ray through window position (x, y)."""
+        ray = np.zeros(6, np.float32); t = C.c_float(); i = C.c_int()
+        pos = np.zeros(3, np.float32); nor = np.zeros(3, np.float32)
+        self.lib.orc_pick(s, C.byref(cam), window_w, window_h, x, y, _fp(ray), C.addressof(t), C.addressof(i), _fp(pos), _fp(nor))
+        return ray, np.float32(t.value), int(i.value), pos, nor
 
     def bounce(self, mat_type, mat_n, rd, nor, rnd):
         rd = np.asarray(rd, np.float32); nor = np.asarray(nor, np.float32); rnd = np.asarray(rnd, np.float32)

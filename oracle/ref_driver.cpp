@@ -135,8 +135,13 @@ static void wallsAndLight(std::vector<Object::Object>& dst) {
 
 extern "C" {
 
+#ifdef ORC_REF_PORTABLE_MATH    // _ref/libtracer_ref_pm.so: sinf/cosf/acosf/powf are oracle/pmath.h's (pm_interpose.c)
+const char* orc_name(void) { return "reference-host-build+portable-math"; }
+int orc_set_math_mode(int mode) { return mode == ORC_MATH_PORTABLE ? 0 : -1; }
+#else
 const char* orc_name(void) { return "reference-host-build"; }
 int orc_set_math_mode(int mode) { return mode == ORC_MATH_LIBM ? 0 : -1; }
+#endif
 
 void* orc_scene_create(int variant, int param, const char* data_dir) {
   g_data_dir = data_dir ? data_dir : "";
@@ -403,6 +408,19 @@ void orc_intersect_object(const void* sc, unsigned obj, const float r6[6], float
   Ray::Ray ray = { V(r6), V(r6+3) };
   Ray::Hit h = Ray::intersect(ray, s->objs[obj]);
   *t = h.m_t; memcpy(pos,&h.m_pos[0],12); memcpy(nor,&h.m_nor[0],12);
+}
+// main.cpp:180-208 (the body of the `pick` block; A, B, C arrive precomputed in `cam`, see oracle_api.h)
+void orc_pick(const void* sc, const orc_camera* cam, int WINDOW_W_, int WINDOW_H_, int x, int y,
+              float ray6[6], float* t, int* id, float pos[3], float nor[3]) {
+  const RefScene* s = (const RefScene*)sc;
+  const glm::vec3 campos = V(cam->campos), A = V(cam->A), B = V(cam->B), C = V(cam->C);
+  Ray::Ray ray;
+  glm::vec2 uv( (float)x/WINDOW_W_, (float)(WINDOW_H_-y)/WINDOW_H_ );                    // :196
+  ray.m_pos = campos+C + (2.0f*uv.x-1.0f)*A + (2.0f*uv.y-1.0f)*B;                        // :198
+  ray.m_dir = glm::normalize(ray.m_pos-campos);                                          // :199
+  Ray::Hit h = Ray::intersectScene(ray, s->objs.data(), s->objs.size());                 // :202
+  memcpy(ray6,&ray.m_pos[0],12); memcpy(ray6+3,&ray.m_dir[0],12);
+  *t = h.m_t; *id = h.m_id; memcpy(pos,&h.m_pos[0],12); memcpy(nor,&h.m_nor[0],12);
 }
 void orc_bounce(int mat_type, float mat_n, const float rd[3], const float nor[3], const float rnd[3], float out[3]) {
   Material::Material m; m.m_type = (Material::Type)mat_type; m.m_n = mat_n;

@@ -822,6 +822,19 @@ void orc_intersect_object(const void* sc, unsigned obj, const float r6[6], float
   Hit h = intersectObject(ray, &s->objs[obj]);
   *t = h.t; memcpy(pos, &h.pos, 12); memcpy(nor, &h.nor, 12);
 }
+/* main.cpp:180-208 */
+void orc_pick(const void* sc, const orc_camera* cam, int window_w, int window_h, int x, int y,
+              float ray6[6], float* t, int* id, float pos[3], float nor[3]) {
+  const Scene* s = (const Scene*)sc;
+  const v3 campos = ldv(cam->campos), A = ldv(cam->A), B = ldv(cam->B), Cc = ldv(cam->C);
+  v2 uv = { (float)x / window_w, (float)(window_h - y) / window_h };                    /* :196 */
+  Ray ray;
+  ray.pos = add3(add3(add3(campos, Cc), scl3(A, 2.0f * uv.x - 1.0f)), scl3(B, 2.0f * uv.y - 1.0f));   /* :198 */
+  ray.dir = normalize3(sub3(ray.pos, campos));                                          /* :199 */
+  Hit h = intersectScene(ray, s->objs, s->n);                                           /* :202 */
+  memcpy(ray6, &ray.pos, 12); memcpy(ray6 + 3, &ray.dir, 12);
+  *t = h.t; *id = h.id; memcpy(pos, &h.pos, 12); memcpy(nor, &h.nor, 12);
+}
 void orc_bounce(int mat_type, float mat_n, const float rd[3], const float nor[3], const float rnd[3], float out[3]) {
   Material m = material_default(); m.type = mat_type; m.n = mat_n;
   v3 o = bounce(&m, ldv(rd), ldv(nor), ldv(rnd));

@@ -127,5 +127,8 @@ int main(int argc, char** argv) {
   f = fopen((out + ".ldr").c_str(), "wb"); fwrite(ldr, sizeof(uint32_t), (size_t)w * h, f); fclose(f);
   trc_write_ppm((out + ".ppm").c_str(), ldr, w, h);
   printf("iterations %u\n", renderer.getIterations());
+  // main.cpp:180-208: what is under the middle of the window, and under its top-left corner region
+  printf("pick centre %d, pick (w/4, h/8) %d\n", renderer.pick(camera, (int)w / 2, (int)h / 2, w, h),
+         renderer.pick(camera, (int)w / 4, (int)h / 8, w, h));
   return renderer.ok() ? 0 : 1;
 }

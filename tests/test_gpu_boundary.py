@@ -113,6 +113,10 @@ def test_cpp_renderer_mirror(ta, tmp_path):
     r = subprocess.run([exe, data, str(w), str(h), str(frames), out, "2"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert f"iterations {frames}" in r.stdout
+    # Renderer::pick (main.cpp:180-208) printed by the program vs trc_pick through ctypes
+    import re
+    m = re.search(r"pick centre (-?\d+), pick \(w/4, h/8\) (-?\d+)", r.stdout)
+    assert m, r.stdout
     film = np.fromfile(out + ".film", np.float32).reshape(-1, 3)
     ldr = np.fromfile(out + ".ldr", np.uint32)
     sc = ta.Scene(0)
@@ -125,6 +129,7 @@ def test_cpp_renderer_mirror(ta, tmp_path):
         tr.pathtrace(cam, int(np.uint64(np.float32(timer * np.float32(100.0)))), it, 1)
     assert tr.read_film().tobytes() == film.tobytes()
     assert np.array_equal(tr.read_ldr(), ldr)
+    assert int(m.group(1)) == tr.pick(cam, w, h, w // 2, h // 2)[0] and int(m.group(2)) == tr.pick(cam, w, h, w // 4, h // 8)[0]
     assert os.path.getsize(out + ".ppm") == len(f"P6\n{w} {h}\n255\n") + 3 * w * h
     # mode 1 through the class, and the batched extension
     r = subprocess.run([exe, data, str(w), str(h), "1", out + "1", "1"], capture_output=True, text=True, timeout=120)

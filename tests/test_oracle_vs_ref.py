@@ -92,3 +92,36 @@ def test_axis_aligned_scene(oracle_c, oracle_ref, product_lib, tmp_path, lens):
         b = oracle_c.pathtrace(s, 64, 64, cam, 5, 1, 4, rng_mode=rng, nthreads=4)
         assert a["film"].tobytes() == b["film"].tobytes() and a["stats"] == b["stats"]
         assert b["stats"]["trans"] > 0 and b["stats"]["mirr"] > 0 and b["stats"]["light"] > 0
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_portable_math_reference_build(oracle_c, oracle_ref, variant):
+    """oracle/_ref/libtracer_ref_pm.so = the reference's own sources with sinf / cosf / sincosf / acosf / powf bound
+    to oracle/pmath.h (oracle/pm_interpose.c). The C restatement in portable-math mode -- the arithmetic the HIP
+    kernels are bit-identical to -- must equal it on film, LDR bytes, statistics and the sampling helpers; the
+    plain build must NOT equal it on the helpers (the interposition is real)."""
+    from oracle import pyoracle
+    if not pyoracle.available("ref_pm"):
+        pytest.skip("oracle/_ref/libtracer_ref_pm.so not built")
+    P = pyoracle.Oracle("ref_pm")
+    assert P.name() == "reference-host-build+portable-math"
+    sp = P.scene_create(variant); sc = oracle_c.scene_create(variant)
+    cam = P.camera_default(112, 80, -0.4, 0.15)
+    oracle_c.set_math_mode(pyoracle.Oracle.MATH_PORTABLE)
+    try:
+        for rng in (0, 1):
+            a = P.pathtrace(sp, 112, 80, cam, 21, 1, 5, rng_mode=rng)
+            b = oracle_c.pathtrace(sc, 112, 80, cam, 21, 1, 5, rng_mode=rng, nthreads=4)
+            assert a["film"].tobytes() == b["film"].tobytes() and np.array_equal(a["pbo"], b["pbo"]) and a["stats"] == b["stats"]
+        rs = np.random.RandomState(3)
+        differs = 0
+        for r in rs.uniform(0, 1, (200, 3)).astype(np.float32):
+            v = P.rand_vector(float(r[0]), float(r[1]))
+            assert v.tobytes() == oracle_c.rand_vector(float(r[0]), float(r[1])).tobytes()
+            assert P.rand_point_disk(*[float(x) for x in r]).tobytes() == oracle_c.rand_point_disk(*[float(x) for x in r]).tobytes()
+            differs += v.tobytes() != oracle_ref.rand_vector(float(r[0]), float(r[1])).tobytes()
+        assert differs > 20
+        films = rs.uniform(0, 20, (100, 3)).astype(np.float32)
+        assert np.array_equal(P.tonemap(films, 7.0), oracle_c.tonemap(films, 7.0))
+    finally:
+        oracle_c.set_math_mode(pyoracle.Oracle.MATH_LIBM)

@@ -154,9 +154,84 @@ def main():
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
-    for fn in sorted(os.listdir(OUT)):
-        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+def make_full(R, P):
+    """Per-sample radiance of the reference host build at the BASELINE.json sizes: configs[1] 512x512 (iterations 1
+    and 7, both RNG modes; a 4-iteration film), configs[2] 1024x1024 glass icosahedron (iteration 1), configs[3]
+    3840x2160 (iteration 1, the whole frame). One sample's radiance is a product of material colours (or zero): the
+    4K frame is stored as a palette of its distinct RGB triples + one index per pixel (exact, ~1.2 MB compressed).
+
+    R = the reference build as it is (glibc sinf/cosf/acosf/powf); P = the same sources with those four bound to
+    oracle/pmath.h (oracle/pm_interpose.c), i.e. the reference's code on the arithmetic the HIP kernels use. Where P's
+    output equals R's byte for byte only a flag is stored (`*_pm_equal`); else the differing pixels (`*_pm_diff_*`)."""
+    d = {}
+    sR = {0: R.scene_create(0, 0), 1: R.scene_create(1, 0)}
+    sP = {0: P.scene_create(0, 0), 1: P.scene_create(1, 0)}
+
+    def sample(key, variant, w, h, cam, it, n, rng):
+        a = R.pathtrace(sR[variant], w, h, cam, 1, it, n, rng_mode=rng)
+        b = P.pathtrace(sP[variant], w, h, cam, 1, it, n, rng_mode=rng)
+        diff = np.nonzero(np.abs(a["film"] - b["film"]).max(1) > 0)[0].astype(np.int64)
+        d[key + "_pm_diff_idx"] = diff
+        d[key + "_pm_diff_val"] = b["film"][diff]
+        return a, b
+
+    c = R.camera_default(512, 512)
+    d["c1_cam"] = c.as_array(); d["c1_shape"] = np.array([512, 512, 0, 0, 1], np.int32)
+    for rng in (0, 1):
+        for it in (1, 7):
+            d[f"c1_rng{rng}_sample{it}"] = sample(f"c1_rng{rng}_sample{it}", 0, 512, 512, c, it, 1, rng)[0]["film"]
+    a, b = sample("c1_rng0_film4", 0, 512, 512, c, 1, 4, 0)
+    d["c1_rng0_film4"] = a["film"]; d["c1_rng0_pbo4"] = a["pbo"]; d["c1_rng0_pbo4_pm"] = b["pbo"]
+    c = R.camera_default(1024, 1024)
+    d["c2_cam"] = c.as_array(); d["c2_shape"] = np.array([1024, 1024, 1, 0, 1], np.int32)
+    d["c2_rng0_sample1"] = sample("c2_rng0_sample1", 1, 1024, 1024, c, 1, 1, 0)[0]["film"]
+    c = R.camera_default(3840, 2160)
+    w, h = 3840, 2160
+    d["c3_cam"] = c.as_array(); d["c3_shape"] = np.array([w, h, 0, 0, 1], np.int32)
+    film = sample("c3_rng0_sample1", 0, w, h, c, 1, 1, 0)[0]["film"]
+    pal, idx = np.unique(film.view(np.dtype((np.void, 12))).ravel(), return_inverse=True)
+    assert len(pal) < 256
+    d["c3_rng0_sample1_palette"] = pal.view(np.float32).reshape(-1, 3)
+    d["c3_rng0_sample1_index"] = idx.astype(np.uint8)
+    assert d["c3_rng0_sample1_palette"][d["c3_rng0_sample1_index"]].tobytes() == film.tobytes()
+    for k in sorted(d):
+        if k.endswith("_pm_diff_idx"):
+            print(k, len(d[k]), "pixels differ between the glibc and the portable-math reference builds")
+    np.savez_compressed(os.path.join(OUT, "mode2_full.npz"), **d)
+
+
+def make_picks(R):
+    """main.cpp:180-208 through the reference build: picking rays of a 512x512 window (WINDOW_W/H, common.h:33-34) on
+    a 23x23 grid of window positions plus the corners, default and rotated camera, default and glass scene."""
+    d = {}
+    xs = list(range(0, 512, 23)) + [511, 512]
+    xy = np.array([(x, y) for y in xs for x in xs], np.int32)
+    d["xy"] = xy; d["window"] = np.array([512, 512], np.int32)
+    for name, variant, cargs in (("v0", 0, (512, 512, 0.0, 0.0)), ("v1_rot", 1, (512, 512, 0.3, -0.2))):
+        s = R.scene_create(variant, 0)
+        c = R.camera_default(*cargs)
+        out = [R.pick(s, c, 512, 512, int(x), int(y)) for x, y in xy]
+        d[name + "_cam"] = c.as_array(); d[name + "_variant"] = np.array([variant], np.int32)
+        d[name + "_ray"] = np.stack([o[0] for o in out]); d[name + "_t"] = np.array([o[1] for o in out], np.float32)
+        d[name + "_id"] = np.array([o[2] for o in out], np.int32)
+        d[name + "_pos"] = np.stack([o[3] for o in out]); d[name + "_nor"] = np.stack([o[4] for o in out])
+    np.savez_compressed(os.path.join(OUT, "picks.npz"), **d)
 
 
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1:]
+    if not which:
+        main()
+    if not which or "full" in which or "picks" in which:
+        Rr = Oracle("ref")
+        assert Rr.name() == "reference-host-build"
+        if not which or "full" in which:
+            Pp = Oracle("ref_pm")
+            assert Pp.name() == "reference-host-build+portable-math"
+            make_full(Rr, Pp)
+        if not which or "picks" in which:
+            make_picks(Rr)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))

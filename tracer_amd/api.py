@@ -16,6 +16,7 @@ ABI_SYMBOLS = [
     "trc_write_film", "trc_read_ldr", "trc_read_hits", "trc_synchronize", "trc_film_device_ptr",
     "trc_bind_film", "trc_set_tile", "trc_get_counters", "trc_reset_counters", "trc_last_render_ms", "trc_last_kernel_ms",
     "trc_last_error_string", "trc_version", "pathtrace", "raytrace1",
+    "trc_intersect_rays", "trc_intersect_rays_device", "trc_pick",
 ]
 # every symbol include/tracer_host.h declares
 HOST_SYMBOLS = [
@@ -99,6 +100,9 @@ def load_library():
     L.trc_update_object.argtypes = [vp, u32, vp, vp]
     L.trc_raytrace1.argtypes = [vp, C.POINTER(Camera)]
     L.trc_pathtrace.argtypes = [vp, C.POINTER(Camera), u64, u32, u32, u32]
+    L.trc_intersect_rays.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    L.trc_intersect_rays_device.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    L.trc_pick.argtypes = [vp, C.POINTER(Camera), u32, u32, i32, i32, C.POINTER(i32), C.POINTER(f32), vp, vp]
     L.trc_reset_film.argtypes = [vp]
     L.trc_tonemap.argtypes = [vp, f32]
     L.trc_read_film.argtypes = [vp, vp]
@@ -212,6 +216,24 @@ class Tracer:
 
     def pathtrace(self, cam, seed, iter_first, n_iters, iter_stride=1):
         self._check(self.L.trc_pathtrace(self.ctx, C.byref(cam), seed, iter_first, iter_stride, n_iters))
+
+    def intersect_rays(self, rays6):
+        """Ray::intersectScene for an (n, 6) float32 array of {pos, dir}: dict(ids, ts, pos, nor)."""
+        r = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
+        n = r.shape[0]
+        ids = np.empty(n, np.int32); ts = np.empty(n, np.float32)
+        pos = np.empty((n, 3), np.float32); nor = np.empty((n, 3), np.float32)
+        self._check(self.L.trc_intersect_rays(self.ctx, _ptr(r), n, _ptr(ids), _ptr(ts), _ptr(pos), _ptr(nor)))
+        return dict(ids=ids, ts=ts, pos=pos, nor=nor)
+
+    def intersect_rays_device(self, rays6_ptr, n, ids_ptr=None, ts_ptr=None, pos_ptr=None, nor_ptr=None):
+        self._check(self.L.trc_intersect_rays_device(self.ctx, rays6_ptr, n, ids_ptr, ts_ptr, pos_ptr, nor_ptr))
+
+    def pick(self, cam, window_w, window_h, x, y):
+        """main.cpp:180-208: (id, t, pos, nor) under window position (x, y), y from the top."""
+        i = C.c_int32(); t = C.c_float(); pos = np.empty(3, np.float32); nor = np.empty(3, np.float32)
+        self._check(self.L.trc_pick(self.ctx, C.byref(cam), window_w, window_h, x, y, C.byref(i), C.byref(t), _ptr(pos), _ptr(nor)))
+        return int(i.value), np.float32(t.value), pos, nor
 
     def reset_film(self):
         self._check(self.L.trc_reset_film(self.ctx))

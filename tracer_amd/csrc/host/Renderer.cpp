@@ -72,6 +72,14 @@ void Renderer::updateScene(int index, const Object::Object& obj) {
   check(trc_update_object(m_ctx, (uint32_t)index, obj.matrix, obj.matrixi), "trc_update_object");
 }
 
+int Renderer::pick(const Camera& camera, int x, int y, unsigned windowW, unsigned windowH) {
+  if (!m_ctx) return -1;
+  trc_camera cam; cameraFrame(camera, &cam);                                    // main.cpp:187-194
+  int32_t id = -1;
+  check(trc_pick(m_ctx, &cam, windowW, windowH, x, y, &id, nullptr, nullptr, nullptr), "trc_pick");
+  return id;
+}
+
 const uint32_t* Renderer::ldr() {
   m_ldr.resize((size_t)image_width * image_height);
   if (m_ctx) check(trc_read_ldr(m_ctx, m_ldr.data()), "trc_read_ldr");

@@ -33,6 +33,9 @@ public:
   // `count` path-tracing iterations in one call (one persistent launch instead of `count`
   // render() calls); equivalent to calling render() `count` times with the same `time`.
   void renderIterations(const Camera& camera, float time, unsigned count);
+  // Picking, main.cpp:180-208 (there on the CPU copy of the scene; here against the uploaded one): the object
+  // under window position (x, y) -- y from the top, as GLUT reports it -- of a windowW x windowH window, or -1.
+  int pick(const Camera& camera, int x, int y, unsigned windowW, unsigned windowH);
   const uint32_t* ldr();       // w*h pixels, 0x00RRGGBB, row 0 = bottom of the image
   const float* film();         // 3*w*h floats, un-normalised radiance sums (divide by getIterations())
   bool ok() const { return m_error.empty(); }

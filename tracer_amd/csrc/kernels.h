@@ -99,6 +99,12 @@ void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, flo
                       float* hit_pos, float* hit_nor, DeviceCounters* counters, const BigMeshPass* bmp,
                       hipStream_t stream);
 
+// Ray::intersectScene for a batch of caller rays (device pointers; rays6[i] = {pos, dir}); outputs may be null;
+// bmp as for launch_raytrace1 (slot = ray index).
+void launch_intersect_rays(const FrameParams& fp, const float* rays6, uint32_t n, int32_t* hit_id, float* hit_t,
+                           float* hit_pos, float* hit_nor, DeviceCounters* counters, const BigMeshPass* bmp,
+                           hipStream_t stream);
+
 // mode 2, wavefront pipelines: a chunk of `n_iters` iterations (iter_first, +stride, ...) in one launch
 // sequence = raygen + kPathDepth bounce launches over ntile * n_iters path slots + k_accumulate.
 // compact = false: state stays at its slot, dead paths flagged (pixel plane = -1).

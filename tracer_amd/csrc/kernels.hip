@@ -180,6 +180,30 @@ __global__ __launch_bounds__(kBlock) void k_raytrace1(FrameParams fp, uint32_t* 
   if (hit_nor) { hit_nor[3 * idx] = hit.nor.x; hit_nor[3 * idx + 1] = hit.nor.y; hit_nor[3 * idx + 2] = hit.nor.z; }
 }
 
+// ---- ray batches: Ray::intersectScene (Ray.inl:66-84) for rays the caller supplies -------------------
+// What main.cpp:202 does on the CPU for one picking ray, for n rays at once: rays6[i] = {pos.xyz, dir.xyz}
+// (the direction as given: intersectScene does not normalise it either). Any output may be null.
+__global__ __launch_bounds__(kBlock) void k_intersect_rays(FrameParams fp, const float* __restrict__ rays6, uint32_t n,
+                                                          int32_t* __restrict__ hit_id, float* __restrict__ hit_t,
+                                                          float* __restrict__ hit_pos, float* __restrict__ hit_nor,
+                                                          DeviceCounters* counters) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;                    // no early return: closest_hit is wave-convergent
+  Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
+  if (valid) { const float* r = rays6 + 6ull * i; ray.pos = mk3(r[0], r[1], r[2]); ray.dir = mk3(r[3], r[4], r[5]); }
+  uint32_t tt = 0;
+  const Hit hit = closest_hit(ray, valid, fp.sc, tt, i, fp.sc.xf);
+  if (counters) {
+    count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
+    count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, valid ? 1ull : 0ull);
+  }
+  if (!valid) return;
+  if (hit_id) hit_id[i] = hit.id;
+  if (hit_t) hit_t[i] = hit.t;
+  if (hit_pos) { hit_pos[3ull * i] = hit.pos.x; hit_pos[3ull * i + 1] = hit.pos.y; hit_pos[3ull * i + 2] = hit.pos.z; }
+  if (hit_nor) { hit_nor[3ull * i] = hit.nor.x; hit_nor[3ull * i + 1] = hit.nor.y; hit_nor[3ull * i + 2] = hit.nor.z; }
+}
+
 // ---- big meshes: brute-force closest triangle as a pass of its own ---------------------------------
 // Ray.inl:172-177 tests EVERY face of a MESH for every ray that passed its AABB. For a mesh of a
 // million triangles that loop is the whole cost of a frame, so the launch-per-bounce pipelines
@@ -212,10 +236,11 @@ constexpr unsigned long long kKeyNone = ((unsigned long long)0x7f7fffffu << 32) 
 
 // SOURCE 0: primary rays of mode 1 (slot = pixel). SOURCE 1: the live paths of a bounce pass
 // (slot = position in the path-state arrays; n_in from the queue counter when compacting).
+// SOURCE 2: a batch of caller rays, rays6[slot] = {pos, dir} (trc_intersect_rays).
 template <int SOURCE>
 __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t mesh_index, uint32_t n_slots, PathState cur,
                                                      const uint32_t* __restrict__ count_in, MeshRayQueue q,
-                                                     unsigned long long* __restrict__ keys) {
+                                                     unsigned long long* __restrict__ keys, const float* __restrict__ rays6) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool live;
   if (SOURCE == 1) {                 // the slots of a wavefront launch sequence, region by region
@@ -231,6 +256,8 @@ __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t m
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
   if (SOURCE == 0) {
     ray = primary_ray(fp, fp.pix0 + i);
+  } else if (SOURCE == 2) {
+    if (live) { const float* r = rays6 + 6ull * i; ray.pos = mk3(r[0], r[1], r[2]); ray.dir = mk3(r[3], r[4], r[5]); }
   } else {
     live = live && cur.pixel[i] >= 0;
     if (live) { ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]); ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]); }
@@ -804,7 +831,7 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float* __restrict__ fi
 // One brute-force pass per big mesh over the rays of the kernel that follows (SOURCE as k_mesh_rays).
 template <int SOURCE>
 static void launch_big_mesh_passes(const FrameParams& fp, uint32_t n_slots, PathState cur, const uint32_t* count_in,
-                                   const BigMeshPass& bmp, hipStream_t stream) {
+                                   const BigMeshPass& bmp, hipStream_t stream, const float* rays6 = nullptr) {
   for (uint32_t b = 0; b < bmp.n_big; ++b) {
     const BigMesh& m = bmp.big[b];
     const uint32_t n_tiles = (m.tri_count + kMeshTile - 1) / kMeshTile;
@@ -814,7 +841,7 @@ static void launch_big_mesh_passes(const FrameParams& fp, uint32_t n_slots, Path
     const uint32_t n_segs = (n_tiles + tiles_per_seg - 1) / tiles_per_seg;
     (void)hipMemsetAsync(bmp.q.count, 0, sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(SOURCE == 1 ? kRegions * (region_cap(n_slots) / kBlock) : grid_for(n_slots)), dim3(kBlock), 0, stream,
-                       fp, m.mesh_index, n_slots, cur, count_in, bmp.q, bmp.keys);
+                       fp, m.mesh_index, n_slots, cur, count_in, bmp.q, bmp.keys, rays6);
     if (bmp.bvh && bmp.bvh[b].nodes) {
       hipLaunchKernelGGL(k_mesh_bvh, dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
                          bmp.q, bmp.bvh[b].nodes, bmp.bvh[b].faces, fp.sc.tris + m.tri_first, bmp.bvh[b].prm,
@@ -835,6 +862,15 @@ void launch_raytrace1(const FrameParams& fp, uint32_t* ldr, int32_t* hit_id, flo
   if (bmp) launch_big_mesh_passes<0>(fp, fp.ntile, PathState{}, nullptr, *bmp, stream);
   hipLaunchKernelGGL(k_raytrace1, dim3(grid_for(fp.ntile)), dim3(kBlock), 0, stream,
                      fp, ldr, hit_id, hit_t, hit_pos, hit_nor, counters);
+}
+
+void launch_intersect_rays(const FrameParams& fp, const float* rays6, uint32_t n, int32_t* hit_id, float* hit_t,
+                           float* hit_pos, float* hit_nor, DeviceCounters* counters, const BigMeshPass* bmp,
+                           hipStream_t stream) {
+  if (n == 0) return;
+  if (bmp) launch_big_mesh_passes<2>(fp, n, PathState{}, nullptr, *bmp, stream, rays6);
+  hipLaunchKernelGGL(k_intersect_rays, dim3(grid_for(n)), dim3(kBlock), 0, stream,
+                     fp, rays6, n, hit_id, hit_t, hit_pos, hit_nor, counters);
 }
 
 void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,

@@ -86,6 +86,9 @@ struct trc_ctx {
   unsigned brute_blocks = 0;
   std::vector<DevBvh> bvh;             // per big mesh, built on first use with TRC_OPT_MESH_ACCEL = 1
 
+  // trc_intersect_rays: device staging of a host ray batch [rays 6n | pos 3n | nor 3n | t n | id n]
+  float* batch_mem = nullptr; size_t batch_cap = 0;
+
   DeviceCounters* counters = nullptr;
 };
 
@@ -421,6 +424,9 @@ int trc_create(int device, uint32_t width, uint32_t height, void* stream, trc_ct
     HIP_TRY(hipMemsetAsync(c->ldr, 0, sizeof(uint32_t) * c->npix, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(DeviceCounters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->resident_blocks = (unsigned)prop.multiProcessorCount * 4u;   // work queue: 4 x 256 threads per CU = 4 waves per SIMD
     return TRC_OK;
   }();
   if (rc != TRC_OK) { trc_destroy(c); return rc; }
@@ -437,7 +443,7 @@ int trc_destroy(trc_ctx* c) {
   free_dev(c->hit_id); free_dev(c->hit_t); free_dev(c->hit_pos); free_dev(c->hit_nor);
   free_dev(c->state_mem[0]); free_dev(c->state_mem[1]); free_dev(c->queue_count);
   free_dev(c->counters); free_dev(c->stage); free_dev(c->next_task);
-  free_dev(c->mesh_keys); free_dev(c->mesh_queue_mem);
+  free_dev(c->mesh_keys); free_dev(c->mesh_queue_mem); free_dev(c->batch_mem);
   free_bvh(c);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
@@ -526,6 +532,68 @@ int trc_raytrace1(trc_ctx* c, const trc_camera* cam) {
   return end_timing(c);
 }
 
+// Ray::intersectScene for caller rays (main.cpp:202 calls it on the CPU for the picking ray).
+int trc_intersect_rays_device(trc_ctx* c, const void* rays6_d, uint32_t n, void* ids_d, void* ts_d,
+                              void* pos3_d, void* nor3_d) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  if (c->nobj == 0) return fail(TRC_ERR_NO_SCENE, "no scene uploaded");
+  if (n == 0) return TRC_OK;
+  if (!rays6_d) return fail(TRC_ERR_INVALID, "trc_intersect_rays: null ray array");
+  if (n > 0x7FFFFFFFu) return fail(TRC_ERR_INVALID, "trc_intersect_rays: more than 2^31 - 1 rays");
+  HIP_TRY(hipSetDevice(c->device));
+  trc_camera none; memset(&none, 0, sizeof none);
+  FrameParams fp = make_params(c, &none, 0);
+  int rc = ensure_big_mesh_buffers(c, n); if (rc) return rc;
+  BigMeshPass bmp = big_mesh_pass(c);
+  const BigMeshPass* pass = c->big.empty() ? nullptr : &bmp;
+  if (pass) { fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = (uint32_t)c->mesh_slots; }
+  launch_intersect_rays(fp, (const float*)rays6_d, n, (int32_t*)ids_d, (float*)ts_d, (float*)pos3_d, (float*)nor3_d,
+                        c->counters, pass, c->stream);
+  HIP_TRY(hipGetLastError());
+  return TRC_OK;
+}
+
+int trc_intersect_rays(trc_ctx* c, const float* rays6, uint32_t n, int32_t* ids, float* ts, float* pos3, float* nor3) {
+  if (!c) return fail(TRC_ERR_INVALID, "null context");
+  if (c->nobj == 0) return fail(TRC_ERR_NO_SCENE, "no scene uploaded");
+  if (n == 0) return TRC_OK;
+  if (!rays6) return fail(TRC_ERR_INVALID, "trc_intersect_rays: null ray array");
+  if (n > 0x7FFFFFFFu) return fail(TRC_ERR_INVALID, "trc_intersect_rays: more than 2^31 - 1 rays");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t need = 14ull * n;               // floats
+  if (need > c->batch_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_dev(c->batch_mem); c->batch_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->batch_mem, sizeof(float) * need));
+    c->batch_cap = need;
+  }
+  float* d_rays = c->batch_mem; float* d_pos = d_rays + 6ull * n; float* d_nor = d_pos + 3ull * n;
+  float* d_t = d_nor + 3ull * n; int32_t* d_id = (int32_t*)(d_t + n);
+  HIP_TRY(hipMemcpyAsync(d_rays, rays6, sizeof(float) * 6ull * n, hipMemcpyHostToDevice, c->stream));
+  int rc = trc_intersect_rays_device(c, d_rays, n, d_id, d_t, d_pos, d_nor); if (rc) return rc;
+  if (ids) HIP_TRY(hipMemcpyAsync(ids, d_id, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (ts) HIP_TRY(hipMemcpyAsync(ts, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (pos3) HIP_TRY(hipMemcpyAsync(pos3, d_pos, sizeof(float) * 3ull * n, hipMemcpyDeviceToHost, c->stream));
+  if (nor3) HIP_TRY(hipMemcpyAsync(nor3, d_nor, sizeof(float) * 3ull * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TRC_OK;
+}
+
+// main.cpp:180-208: the pixel-corner ray through window position (x, y), y counted from the top as GLUT reports it.
+int trc_pick(trc_ctx* c, const trc_camera* cam, uint32_t window_w, uint32_t window_h, int32_t x, int32_t y,
+             int32_t* id, float* t, float* pos3, float* nor3) {
+  if (!c || !cam) return fail(TRC_ERR_INVALID, "null argument");
+  if (window_w == 0 || window_h == 0 || window_w > 0x7FFFFFFFu || window_h > 0x7FFFFFFFu)
+    return fail(TRC_ERR_INVALID, "trc_pick: bad window size");
+  const int W = (int)window_w, H = (int)window_h;
+  const float u = (float)x / W, v = (float)(H - y) / H;                                  // main.cpp:196
+  const f3 campos = ld3(cam->campos), A = ld3(cam->A), B = ld3(cam->B), Cc = ld3(cam->C);
+  const f3 pos = campos + Cc + (2.0f * u - 1.0f) * A + (2.0f * v - 1.0f) * B;           // :198
+  const f3 dir = normalize(pos - campos);                                                // :199
+  const float ray6[6] = { pos.x, pos.y, pos.z, dir.x, dir.y, dir.z };
+  return trc_intersect_rays(c, ray6, 1, id, t, pos3, nor3);                              // :202
+}
+
 int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
                   uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters) {
   if (!c || !cam) return fail(TRC_ERR_INVALID, "null argument");
@@ -576,14 +644,7 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
       fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = (uint32_t)c->mesh_slots;
     }
   }
-  if (pipeline == TRC_PIPE_QUEUE) {
-    if (!c->next_task) HIP_TRY(hipMalloc((void**)&c->next_task, sizeof(uint32_t)));
-    if (!c->resident_blocks) {
-      hipDeviceProp_t prop;
-      HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-      c->resident_blocks = (unsigned)prop.multiProcessorCount * 4u;   // 4 x 256 threads per CU = 4 waves per SIMD
-    }
-  }
+  if (pipeline == TRC_PIPE_QUEUE && !c->next_task) HIP_TRY(hipMalloc((void**)&c->next_task, sizeof(uint32_t)));
   int rc = begin_timing(c); if (rc) return rc;
   if (pipeline == TRC_PIPE_QUEUE) {
     for (uint32_t done = 0; done < n_iters; done += chunk_iters) {
