@@ -134,6 +134,19 @@ int trc_raytrace1(trc_ctx* ctx, const trc_camera* cam);
  * reference's last accumColorKernel (raytrace.cu:173). seed keys the RNG (rng.h).          */
 int trc_pathtrace(trc_ctx* ctx, const trc_camera* cam, uint64_t seed,
                   uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters);
+/* trc_pathtrace for callers that cannot allocate. NO COUNTERPART IN THE REFERENCE (whose launcher owns no memory
+ * at all, raytrace.cu:189-226): it is for code under HIP graph capture, tight serving loops and harnesses that
+ * forbid hipMalloc. Runs the work-queue pipeline (TRC_PIPE_QUEUE) with its scratch -- the task counter and the
+ * 12-bytes-per-path sample staging -- in a static device array of 64 MiB + 256 B that every GPU the library runs on
+ * holds until the process ends; the call itself performs no hipMalloc / hipFree / allocating library call. The film
+ * and LDR image are those of the context (or trc_bind_film), bit-identical to trc_pathtrace's.
+ * Limits: one iteration of the rendered tile must fit the staging area, i.e. at most 5 592 405 pixels per
+ * trc_set_tile band (TRC_ERR_UNSUPPORTED beyond; a 3840x2160 frame takes two bands); more iterations than fit
+ * are rendered in chunks. All contexts on one GPU share that GPU's array: calls that overlap in time on one GPU
+ * (different streams or threads) race -- serialise them. */
+int trc_pathtrace_static(trc_ctx* ctx, const trc_camera* cam, uint64_t seed,
+                         uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters);
+
 /* ---- ray queries (the interactive path's picking, main.cpp:180-208) ------------------------ */
 /* Ray::intersectScene (Ray.inl:66-84) for n caller rays against the uploaded scene -- what main.cpp:202 does on
  * the CPU for the picking ray. rays6[i] = {pos.xyz, dir.xyz}, the direction used as given (intersectScene does

@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "trc_write_film", "trc_read_ldr", "trc_read_hits", "trc_synchronize", "trc_film_device_ptr",
     "trc_bind_film", "trc_set_tile", "trc_get_counters", "trc_reset_counters", "trc_last_render_ms", "trc_last_kernel_ms",
     "trc_last_error_string", "trc_version", "pathtrace", "raytrace1",
-    "trc_intersect_rays", "trc_intersect_rays_device", "trc_pick",
+    "trc_intersect_rays", "trc_intersect_rays_device", "trc_pick", "trc_pathtrace_static",
 ]
 # every symbol include/tracer_host.h declares
 HOST_SYMBOLS = [
@@ -100,6 +100,7 @@ def load_library():
     L.trc_update_object.argtypes = [vp, u32, vp, vp]
     L.trc_raytrace1.argtypes = [vp, C.POINTER(Camera)]
     L.trc_pathtrace.argtypes = [vp, C.POINTER(Camera), u64, u32, u32, u32]
+    L.trc_pathtrace_static.argtypes = [vp, C.POINTER(Camera), u64, u32, u32, u32]
     L.trc_intersect_rays.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.trc_intersect_rays_device.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.trc_pick.argtypes = [vp, C.POINTER(Camera), u32, u32, i32, i32, C.POINTER(i32), C.POINTER(f32), vp, vp]
@@ -216,6 +217,10 @@ class Tracer:
 
     def pathtrace(self, cam, seed, iter_first, n_iters, iter_stride=1):
         self._check(self.L.trc_pathtrace(self.ctx, C.byref(cam), seed, iter_first, iter_stride, n_iters))
+
+    def pathtrace_static(self, cam, seed, iter_first, n_iters, iter_stride=1):
+        """trc_pathtrace_static: the work-queue pipeline with its scratch in the library's static device array."""
+        self._check(self.L.trc_pathtrace_static(self.ctx, C.byref(cam), seed, iter_first, iter_stride, n_iters))
 
     def intersect_rays(self, rays6):
         """Ray::intersectScene for an (n, 6) float32 array of {pos, dir}: dict(ids, ts, pos, nor)."""

@@ -37,6 +37,36 @@ template <typename T> void free_dev(T*& p) { if (p) { (void)hipFree(p); p = null
 
 } // namespace
 
+// ---- static scratch of trc_pathtrace_static (include/tracer_abi.h) ---------------------------------------
+// The work-queue pipeline's scratch -- the task counter and the per-path sample staging that trc_pathtrace
+// keeps in hipMalloc'ed buffers -- as a file-scope device array, for callers that cannot allocate. Every GPU
+// the library runs on holds its own copy (at its own address) until the process ends. In host code the
+// array's NAME is only a handle for hipGetSymbolAddress: the address a kernel may use is the one that call
+// returns on the device that is current, resolved once per device in trc_create and kept in g_scratch_ptr.
+constexpr size_t kScratchHeader = 256;                         // [0, 4): the work queue's next-task counter
+constexpr size_t kScratchStageBytes = size_t(64) << 20;        // sample staging: 12 bytes per path of a chunk
+static __device__ __align__(256) unsigned char scratch[kScratchHeader + kScratchStageBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};                         // per device: where `scratch` lives there
+
+// `device` must be current. Resolves the device's copy of `scratch` on first use.
+int resolve_scratch(int device, void** out) {
+  if (device < 0 || device >= kMaxDevices) return fail(TRC_ERR_UNSUPPORTED, "device index beyond the static-scratch table");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(TRC_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return TRC_OK;
+}
+} // namespace
+
 struct trc_ctx {
   int device = 0;
   uint32_t w = 0, h = 0, npix = 0;
@@ -88,6 +118,8 @@ struct trc_ctx {
 
   // trc_intersect_rays: device staging of a host ray batch [rays 6n | pos 3n | nor 3n | t n | id n]
   float* batch_mem = nullptr; size_t batch_cap = 0;
+
+  unsigned char* scratch_d = nullptr;  // this device's copy of the static `scratch` array (trc_pathtrace_static)
 
   DeviceCounters* counters = nullptr;
 };
@@ -427,6 +459,9 @@ int trc_create(int device, uint32_t width, uint32_t height, void* stream, trc_ct
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     c->resident_blocks = (unsigned)prop.multiProcessorCount * 4u;   // work queue: 4 x 256 threads per CU = 4 waves per SIMD
+    void* sp = nullptr;
+    { int rs = resolve_scratch(c->device, &sp); if (rs != TRC_OK) return rs; }
+    c->scratch_d = (unsigned char*)sp;
     return TRC_OK;
   }();
   if (rc != TRC_OK) { trc_destroy(c); return rc; }
@@ -662,6 +697,48 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
                              compact ? c->state[1] : c->state[0], c->queue_count,
                              c->film, c->stage, c->counters, pass, c->stream);
     }
+  }
+  HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+  launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
+  HIP_TRY(hipGetLastError());
+  return end_timing(c);
+}
+
+// The work-queue pipeline of trc_pathtrace with its scratch in the static device array: no hipMalloc, no hipFree,
+// no allocating library call on this path (the context, its film and the scene were allocated by trc_create /
+// trc_upload_scene). Same kernels, same chunking rule, same film bit for bit.
+int trc_pathtrace_static(trc_ctx* c, const trc_camera* cam, uint64_t seed,
+                         uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters) {
+  if (!c || !cam) return fail(TRC_ERR_INVALID, "null argument");
+  if (c->nobj == 0) return fail(TRC_ERR_NO_SCENE, "no scene uploaded");
+  if (iter_first == 0) return fail(TRC_ERR_INVALID, "trc_pathtrace_static: iterations are 1-based");
+  if (n_iters == 0) return TRC_OK;
+  if (n_iters > 1 && iter_stride == 0) return fail(TRC_ERR_INVALID, "trc_pathtrace_static: zero stride");
+  if ((uint64_t)iter_first + (uint64_t)(n_iters - 1) * iter_stride > 0xFFFFFFFFull)
+    return fail(TRC_ERR_INVALID, "trc_pathtrace_static: iteration number overflows 32 bits");
+  if (!c->scratch_d || !c->resident_blocks) return fail(TRC_ERR_UNSUPPORTED, "trc_pathtrace_static: no static scratch on this device");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameParams fp = make_params(c, cam, seed);
+  const size_t per_iter = sizeof(float) * 3ull * fp.ntile;       // staging of one iteration of the tile
+  if (per_iter > kScratchStageBytes)
+    return fail(TRC_ERR_UNSUPPORTED, "trc_pathtrace_static: one iteration of " + std::to_string(fp.ntile) +
+                " pixels needs " + std::to_string(per_iter) + " bytes of sample staging, the static scratch holds " +
+                std::to_string(kScratchStageBytes) + " (5592405 pixels): render in bands (trc_set_tile) or call trc_pathtrace");
+  const uint32_t last_iter = iter_first + (n_iters - 1) * iter_stride;
+  size_t fit = kScratchStageBytes / per_iter;
+  const size_t cap31 = 0x7FFFFFFFull / fp.ntile;
+  if (fit > cap31) fit = cap31;
+  const uint32_t chunk_iters = (uint32_t)(fit < n_iters ? fit : n_iters);
+  // the addresses the kernels use come from hipGetSymbolAddress (c->scratch_d), never from the array's name
+  uint32_t* next_task = reinterpret_cast<uint32_t*>(c->scratch_d);
+  float* stage = reinterpret_cast<float*>(c->scratch_d + kScratchHeader);
+  int rc = begin_timing(c); if (rc) return rc;
+  for (uint32_t done = 0; done < n_iters; done += chunk_iters) {
+    const uint32_t n = (n_iters - done < chunk_iters) ? n_iters - done : chunk_iters;
+    // launch_queue zeroes the task counter (stream-ordered) before every launch; k_queue writes every sample of the
+    // chunk before k_accumulate reads it, so whatever an earlier call left in the staging area is never read
+    launch_queue(fp, iter_first + done * iter_stride, iter_stride, n, c->film, stage, next_task,
+                 c->resident_blocks, c->counters, c->stream);
   }
   HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
   launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
