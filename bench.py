@@ -173,20 +173,29 @@ def main():
     film = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)   # torch owns the film so RCCL can reduce it
     tr.bind_film(film.data_ptr())
 
+    from tracer_amd import multi
+
+    class _HostReduce:
+        """Rehearsal only (all ranks on one GPU): RCCL refuses two ranks on one device, so the sum goes over gloo
+        through the host. Same interface as torch.distributed for multi.reduce_film."""
+        @staticmethod
+        def is_available(): return True
+        @staticmethod
+        def is_initialized(): return True
+        @staticmethod
+        def get_world_size(): return world
+        ReduceOp = dist.ReduceOp
+        @staticmethod
+        def reduce(t, dst=0, op=None):
+            host = t.cpu()
+            dist.reduce(host, dst=dst, op=op)
+            if rank == dst:
+                t.copy_(host)
+
     def step():
-        film.zero_()
-        # rank r renders iterations r+1, r+1+world, ...  (ITERS of them)
-        tr.pathtrace(cam, SEED, rank + 1, ITERS, iter_stride=world)
-        if world > 1:
-            if rehearsal:                    # gloo: through the host
-                host = film.cpu()
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                if rank == 0:
-                    film.copy_(host)
-            else:
-                dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                tr.tonemap(ITERS * world)
+        # the product's own multi-GPU entry: zero the film, render iterations rank+1, rank+1+world, ... of
+        # ITERS x world, ONE sum-reduce to rank 0, display transform there (tracer_amd/multi.py)
+        multi.render_partitioned(tr, cam, SEED, ITERS * world, film, rank, world, _HostReduce if rehearsal else dist)
 
     def fence():
         if world > 1:

@@ -202,7 +202,11 @@ const char* trc_version(void);
  * (Renderer.cpp:94-100), in the reference's layouts; `scene_d` is the device copy of Object[]
  * produced by Renderer::initScene (Renderer.cpp:112-151). `time` seeds the RNG as
  * (uint64)(time*100.0f) like curandSetPseudoRandomGeneratorSeed (raytrace.cu:205);
- * `rand_d` is accepted and left untouched (the RNG is counter-based).                     */
+ * `rand_d` is accepted and left untouched (the RNG is counter-based).
+ * The library keeps a flattened copy of each `scene_d` it has seen and re-validates it on every call with a
+ * content digest computed on the GPU over the objects, their Mesh headers and the mesh arrays (one small kernel,
+ * 8 bytes read back): Renderer::updateScene's in-place edits (Renderer.cpp:221-225), a mesh freed and replaced at
+ * the same address, vertices rewritten in place are all picked up by the next frame.                        */
 void pathtrace(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
                const float* campos, const float* A, const float* B, const float* C,
                float lensRadius, float focalDist,
@@ -212,6 +216,13 @@ void pathtrace(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
 void raytrace1(uint32_t* pbo_out, uint32_t w, uint32_t h, float time,
                const float* campos, const float* A, const float* B, const float* C,
                const void* scene_d, uint32_t sceneSize);
+
+/* Housekeeping for the two launchers above (no counterpart in the reference, which never frees its scene,
+ * Renderer.cpp:109): forget the copy kept for `scene_d` (NULL: for every scene) so that the next call reads it
+ * back unconditionally; free everything the launchers have cached (call before unloading the library -- nothing
+ * is freed behind the caller's back at exit). */
+int trc_legacy_invalidate(const void* scene_d);
+int trc_legacy_release(void);
 
 #ifdef __cplusplus
 }

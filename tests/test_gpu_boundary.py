@@ -142,3 +142,87 @@ def test_cpp_renderer_mirror(ta, tmp_path):
     tr.pathtrace(cam, 1, 1, 4)            # time = 0.01 -> seed (uint64)(0.01f*100) = 1
     assert tr.read_film().tobytes() == np.fromfile(out + "b.film", np.float32).tobytes()
     tr.close()
+
+
+def test_legacy_launchers_notice_a_mesh_swapped_in_place(ta, oracle_c, tmp_path):
+    """The shim behind the reference's signatures keeps a flattened copy of `scene_d`. A mesh whose arrays are
+    rewritten in place -- what a freed scene and a new Mesh landing at the same addresses look like -- must be
+    rendered as it is NOW: same pointers, same counts, other vertices. Also: an unchanged scene is not read back
+    again (the digest path), trc_legacy_invalidate / trc_legacy_release work, and a frame through the legacy
+    signature costs about what the fused frame costs."""
+    import time
+    import torch
+    L = ta.load_library()
+    w, h = 128, 96
+    n = w * h
+    # scene B = the Cornell box with a squashed icosahedron: same counts, other vertices and bounds
+    src = open(os.path.join(REPO, "tracer_amd", "data", "icosahedron.obj")).read().splitlines()
+    out = []
+    for ln in src:
+        if ln.startswith("v "):
+            x, y, z = [float(t) for t in ln.split()[1:]]
+            ln = "v %.6f %.6f %.6f" % (x * 1.25, y * 0.5, z * 0.75)
+        out.append(ln)
+    squashed = tmp_path / "squashed.obj"; squashed.write_text("\n".join(out) + "\n")
+    sc_a = ta.Scene(0)
+    sc_b = ta.Scene(0)
+    k = sc_b.add_obj(str(squashed))
+    raw_b = bytearray(sc_b.raw_objects())
+    meshp_b = struct.unpack("Q", raw_b[168 * k + 128:168 * k + 136])[0]
+    mesh_b = C.string_at(meshp_b, 72)
+    scene_d, keep = _device_scene(torch, sc_a.raw_objects(), sc_a.size)
+    cam = ta.camera_default(w, h)
+    f3 = C.c_float * 3
+    args_cam = [f3(*cam.campos), f3(*cam.A), f3(*cam.B), f3(*cam.C)]
+    vp = C.c_void_p
+    L.raytrace1.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float, f3, f3, f3, f3, vp, C.c_uint32]
+    L.raytrace1.restype = None
+    pbo = torch.zeros(n, dtype=torch.int32, device="cuda")
+
+    def frame():
+        L.raytrace1(pbo.data_ptr(), w, h, 0.0, *args_cam, scene_d.data_ptr(), sc_a.size)
+        torch.cuda.synchronize()
+        return pbo.cpu().numpy().view(np.uint32)
+
+    ocam = oracle_c.camera_default(w, h)
+    ref_a = oracle_c.raytrace1(oracle_c.scene_create(0), w, h, ocam)["pbo"]
+    assert np.array_equal(frame(), ref_a)
+    assert np.array_equal(frame(), ref_a)            # second frame: the digest matches, nothing is read back
+    # overwrite the icosahedron's device arrays and its header's bounds IN PLACE with scene B's mesh
+    obj8 = sc_a.raw_objects()[168 * 8:168 * 9]
+    mesh_d_ptr = struct.unpack("Q", bytes(scene_d[168 * 8 + 128:168 * 8 + 136].cpu().numpy()))[0]
+    mesh_t = next(t for t in keep if t.data_ptr() == mesh_d_ptr)
+    hdr = bytearray(mesh_t.cpu().numpy().tobytes())
+    nv, nn, nf = struct.unpack("III", hdr[0:12]); pv, pn, pf = struct.unpack("QQQ", hdr[16:40])
+    assert (nv, nn, nf) == struct.unpack("III", mesh_b[0:12])
+    bv = struct.unpack("Q", mesh_b[16:24])[0]
+    verts_t = next(t for t in keep if t.data_ptr() == pv)
+    verts_t.copy_(torch.frombuffer(bytearray(C.string_at(bv, 12 * nv)), dtype=torch.uint8).cuda())
+    hdr[40:64] = mesh_b[40:64]                        # m_bmin, m_bmax
+    mesh_t.copy_(torch.frombuffer(hdr, dtype=torch.uint8).cuda())
+    torch.cuda.synchronize()
+    # the oracle's view of the edited scene: object 8 now uses scene B's mesh (host copy), everything else as before
+    raw_mix = bytearray(sc_a.raw_objects())
+    raw_mix[168 * 8 + 128:168 * 8 + 136] = struct.pack("Q", meshp_b)
+    buf = C.create_string_buffer(bytes(raw_mix), len(raw_mix))
+    s_mix = oracle_c.scene_wrap(C.addressof(buf), sc_a.size)
+    ref_b = oracle_c.raytrace1(s_mix, w, h, ocam)["pbo"]
+    assert not np.array_equal(ref_a, ref_b)
+    assert np.array_equal(frame(), ref_b)
+    assert obj8 == sc_a.raw_objects()[168 * 8:168 * 9]
+    # housekeeping entry points
+    assert L.trc_legacy_invalidate(scene_d.data_ptr()) == 0
+    assert np.array_equal(frame(), ref_b)
+    # cost of a frame through the legacy signature (digest + launch), reported, loosely bounded
+    for _ in range(5):
+        frame()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        L.raytrace1(pbo.data_ptr(), w, h, 0.0, *args_cam, scene_d.data_ptr(), sc_a.size)
+    torch.cuda.synchronize()
+    per_frame_ms = (time.perf_counter() - t0) / 50 * 1e3
+    print(f"legacy raytrace1 frame {w}x{h}: {per_frame_ms:.3f} ms")
+    assert per_frame_ms < 5.0
+    assert L.trc_legacy_release() == 0
+    assert np.array_equal(frame(), ref_b)             # and it comes back after a release
+    assert L.trc_legacy_release() == 0

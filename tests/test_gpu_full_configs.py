@@ -137,3 +137,34 @@ def test_config5_icosphere_1310720_triangles_1024x1024(ta, oracle_c):
     assert tr.read_film().tobytes() == a.tobytes()
     assert np.isfinite(a).all()
     tr.close()
+
+
+@pytest.mark.parametrize("by_tile", [False, True])
+@pytest.mark.parametrize("own_stream", [True, False])
+def test_render_partitioned_orders_its_streams(ta, by_tile, own_stream):
+    """tracer_amd.multi.render_partitioned (what bench.py and a multi-GPU caller run) with one rank: a Tracer on a
+    PRIVATE stream (film.zero_() and the tracer's launches are then on different streams and the function must
+    order them itself) and a Tracer on torch's current stream; sample split and image-tile split. The film is
+    the plain trc_pathtrace film, every time, although it starts from garbage."""
+    import torch
+    from tracer_amd import multi
+    w, h, iters = 512, 512, 24
+    sc = ta.Scene(0)
+    cam = ta.camera_default(w, h)
+    with ta.Tracer(w, h) as ref:
+        ref.upload_scene(sc.objects_ptr, sc.size)
+        ref.pathtrace(cam, 4, 1, iters)
+        want = ref.read_film(); want_ldr = ref.read_ldr()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        tr = ta.Tracer(w, h) if own_stream else ta.Tracer(w, h, stream=stream.cuda_stream)
+        tr.upload_scene(sc.objects_ptr, sc.size)
+        film = torch.empty(w * h * 3, dtype=torch.float32, device="cuda")
+        tr.bind_film(film.data_ptr())
+        for _ in range(3):
+            film.fill_(7.0)                    # garbage that a render overtaking the zero_() would keep
+            multi.render_partitioned(tr, cam, 4, iters, film, 0, 1, None, by_tile=by_tile)
+            tr.synchronize(); stream.synchronize()
+            assert film.cpu().numpy().tobytes() == want.tobytes()
+            assert np.array_equal(tr.read_ldr(), want_ldr)
+        tr.close()

@@ -1,7 +1,7 @@
 """Multi-GPU path on CPU: sample-index partition across ranks + ONE sum-reduce of the films
-(tracer_amd/multi.py), exercised with world_size 2 over gloo. The per-rank compute is done by
-the oracle here (no GPU in this container); what is under test is the partition/reduce logic
-bench.py and the 8-GPU runs use."""
+(tracer_amd/multi.py: render_partitioned, the function bench.py and the 8-GPU runs call), exercised
+with world_size 2 and 3 over gloo. The per-rank compute is done by the oracle behind a stand-in for
+the Tracer (no GPU in this container); what is under test is the partition / ordering / reduce logic."""
 import os
 import socket
 
@@ -37,6 +37,42 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+class _OracleTracer:
+    """Stands in for tracer_amd.Tracer on a machine without a GPU: the calls multi.render_partitioned makes
+    (pathtrace into the bound film, set_tile, synchronize, tonemap), computed by the oracle into a CPU tensor.
+    What is under test is the product function's partition / ordering / reduce logic, not this stub."""
+
+    def __init__(self, oracle, w, h, film_tensor):
+        self.o, self.w, self.h = oracle, w, h
+        self.s = oracle.scene_create(0)
+        self.film = film_tensor.numpy().reshape(w * h, 3)      # shares memory with the tensor
+        self.tile = None
+        self.stream_handle = None
+        self.calls = []
+
+    def set_tile(self, row0, rows):
+        self.tile = (row0, rows) if rows else None
+        self.calls.append(("tile", row0, rows))
+
+    def pathtrace(self, cam, seed, iter_first, n_iters, iter_stride=1):
+        self.calls.append(("pathtrace", iter_first, n_iters, iter_stride))
+        if self.tile is None:
+            self.o.pathtrace(self.s, self.w, self.h, cam, seed, iter_first, n_iters, iter_stride=iter_stride,
+                             film=self.film, want_pbo=False)
+        else:     # the oracle renders whole frames: cut this band out of one (trc_set_tile renders only the band)
+            whole = np.zeros((self.w * self.h, 3), np.float32)
+            self.o.pathtrace(self.s, self.w, self.h, cam, seed, iter_first, n_iters, iter_stride=iter_stride,
+                             film=whole, want_pbo=False)
+            y0, rows = self.tile
+            self.film[y0 * self.w:(y0 + rows) * self.w] += whole[y0 * self.w:(y0 + rows) * self.w]
+
+    def synchronize(self):
+        self.calls.append(("sync",))
+
+    def tonemap(self, iters):
+        self.calls.append(("tonemap", iters))
+
+
 def _worker(rank, world, port, total_iters, w, h, seed, out_dir, by_tile=False):
     import torch
     import torch.distributed as dist
@@ -44,22 +80,15 @@ def _worker(rank, world, port, total_iters, w, h, seed, out_dir, by_tile=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     o = Oracle("c")
-    s = o.scene_create(0)
-    cam = o.camera_default(w, h)
-    first, stride, count = multi.rank_iterations(total_iters, rank, world)
-    film = np.zeros((w * h, 3), np.float32)
-    if by_tile:
-        # image-tile partition: this rank's band of rows of every iteration, zero elsewhere (the oracle
-        # renders whole frames, so the band is cut out of one; on the GPU trc_set_tile renders only it)
-        y0, y1 = multi.tile_rows(h, rank, world)
-        whole = o.pathtrace(s, w, h, cam, seed, 1, total_iters, want_pbo=False)["film"].reshape(h, w, 3)
-        film = film.reshape(h, w, 3); film[y0:y1] = whole[y0:y1]; film = film.reshape(w * h, 3)
-    elif count:
-        film = o.pathtrace(s, w, h, cam, seed, first, count, iter_stride=stride, film=film, want_pbo=False)["film"]
-    t = torch.from_numpy(film)
-    multi.reduce_film(t, dist, 0)
+    film = torch.full((w * h * 3,), 3.0, dtype=torch.float32)      # garbage: render_partitioned must zero it
+    tr = _OracleTracer(o, w, h, film)
+    multi.render_partitioned(tr, o.camera_default(w, h), seed, total_iters, film, rank, world, dist, by_tile=by_tile)
+    names = [c[0] for c in tr.calls]
+    assert names.index("sync") > names.index("pathtrace")           # the render is awaited before the reduce
+    assert (("tonemap", total_iters) in tr.calls) == (rank == 0)
+    assert tr.tile is None                                          # the tile is always reset
     if rank == 0:
-        np.save(os.path.join(out_dir, "film.npy"), t.numpy())
+        np.save(os.path.join(out_dir, "film.npy"), film.numpy().reshape(w * h, 3))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -17,6 +17,7 @@ ABI_SYMBOLS = [
     "trc_bind_film", "trc_set_tile", "trc_get_counters", "trc_reset_counters", "trc_last_render_ms", "trc_last_kernel_ms",
     "trc_last_error_string", "trc_version", "pathtrace", "raytrace1",
     "trc_intersect_rays", "trc_intersect_rays_device", "trc_pick", "trc_pathtrace_static",
+    "trc_legacy_invalidate", "trc_legacy_release",
 ]
 # every symbol include/tracer_host.h declares
 HOST_SYMBOLS = [
@@ -104,6 +105,8 @@ def load_library():
     L.trc_intersect_rays.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.trc_intersect_rays_device.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.trc_pick.argtypes = [vp, C.POINTER(Camera), u32, u32, i32, i32, C.POINTER(i32), C.POINTER(f32), vp, vp]
+    L.trc_legacy_invalidate.argtypes = [vp]
+    L.trc_legacy_release.argtypes = []
     L.trc_reset_film.argtypes = [vp]
     L.trc_tonemap.argtypes = [vp, f32]
     L.trc_read_film.argtypes = [vp, vp]
@@ -155,6 +158,7 @@ class Tracer:
         self.L = load_library()
         self.w, self.h, self.npix = int(width), int(height), int(width) * int(height)
         self.ctx = C.c_void_p()
+        self.stream_handle = int(stream) if stream else None     # the caller's hipStream_t, or None: a private stream
         self._check(self.L.trc_create(device, width, height, stream, C.byref(self.ctx)))
 
     def _check(self, rc):

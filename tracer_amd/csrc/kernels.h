@@ -129,6 +129,10 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
                   float* film, float* stage, uint32_t* next_task, unsigned resident_blocks,
                   DeviceCounters* counters, hipStream_t stream);
 
+// 64-bit content digest of a device-resident Object[] in the reference's layout (objects, mesh headers, mesh
+// arrays) into *out (device memory); see k_scene_digest.
+void launch_scene_digest(const void* scene_d, uint32_t n_objects, unsigned long long* out, hipStream_t stream);
+
 // display transform (raytrace.cu:173) over the whole film.
 void launch_tonemap(const float* film, uint32_t npix, float iters, uint32_t* ldr, hipStream_t stream);
 

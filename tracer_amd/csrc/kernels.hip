@@ -19,6 +19,7 @@
 namespace trc {
 
 constexpr int kBlock = 256;
+constexpr unsigned kDigestParts = 32;     // workgroups per object of k_scene_digest
 #ifndef TRC_GATHER_MAX
 #define TRC_GATHER_MAX 16
 #endif
@@ -826,6 +827,45 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float* __restrict__ fi
   ldr[idx] = tonemap(mk3(film[3 * idx], film[3 * idx + 1], film[3 * idx + 2]), iters);
 }
 
+// ---- content digest of a caller-owned device scene (legacy launchers, tracer_abi.hip) ----------------
+// The reference's pathtrace / raytrace1 receive `scene_d`, the device copy of Object[] that Renderer::initScene
+// built (Renderer.cpp:112-151), every frame, and Renderer::updateScene edits it in place (:221-225). The shim
+// behind those signatures keeps a flattened copy of the scene; this kernel tells it whether that copy is still
+// good without reading anything back: a 64-bit sum over EVERY dword the scene consists of -- the Object records,
+// the Mesh headers they point to and, for a MESH, its vertex / normal / face arrays -- each mixed with its
+// position, so a moved matrix, a swapped material, a re-pointed or re-filled mesh array all change it.
+// grid = (objects, kDigestParts); a MESH's arrays are spread over the kDigestParts workgroups of its object.
+__device__ __forceinline__ unsigned long long digest_mix(uint32_t word, uint32_t index, uint32_t tag, uint32_t obj) {
+  unsigned long long z = ((unsigned long long)word | ((unsigned long long)index << 32)) ^
+                         (0x9E3779B97F4A7C15ull * (tag + 1u) + 0xD1B54A32D192ED03ull * (obj + 1u));
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void k_scene_digest(const RefObject* __restrict__ objs, unsigned long long* __restrict__ out) {
+  const uint32_t o = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+  const uint32_t t = part * kBlock + threadIdx.x, stride = nparts * kBlock;
+  unsigned long long h = 0ull;
+  const uint32_t* ow = reinterpret_cast<const uint32_t*>(objs + o);
+  if (part == 0 && threadIdx.x < sizeof(RefObject) / 4) h += digest_mix(ow[threadIdx.x], threadIdx.x, 1u, o);
+  const RefMesh* m = objs[o].mesh;
+  if (m != nullptr) {
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(m);
+    if (part == 0 && threadIdx.x < sizeof(RefMesh) / 4) h += digest_mix(mw[threadIdx.x], threadIdx.x, 2u, o);
+    if (m->type == REF_MESH) {
+      const uint32_t nv = 3u * m->numVerts, nn = 3u * m->numNorms, nf = 6u * m->numFaces;
+      const uint32_t* v = reinterpret_cast<const uint32_t*>(m->verts);
+      const uint32_t* n = reinterpret_cast<const uint32_t*>(m->norms);
+      const uint32_t* f = reinterpret_cast<const uint32_t*>(m->faces);
+      if (v) for (uint32_t i = t; i < nv; i += stride) h += digest_mix(v[i], i, 3u, o);
+      if (n) for (uint32_t i = t; i < nn; i += stride) h += digest_mix(n[i], i, 4u, o);
+      if (f) for (uint32_t i = t; i < nf; i += stride) h += digest_mix(f[i], i, 5u, o);
+    }
+  }
+  h = wave_sum_u64(h);
+  if (lane_id() == 0 && h) atomicAdd(out, h);
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 
 // One brute-force pass per big mesh over the rays of the kernel that follows (SOURCE as k_mesh_rays).
@@ -922,6 +962,12 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
   hipLaunchKernelGGL((lds_gather ? k_queue<true> : k_queue<false>), dim3(blocks), dim3(kBlock), 0, stream, qa);
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(3u * fp.ntile)), dim3(kBlock), 0, stream,
                      film + 3ull * fp.pix0, (const float*)stage, fp.ntile, n_iters, iter_first == 1u ? 1 : 0);
+}
+
+void launch_scene_digest(const void* scene_d, uint32_t n_objects, unsigned long long* out, hipStream_t stream) {
+  (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), stream);
+  hipLaunchKernelGGL(k_scene_digest, dim3(n_objects, kDigestParts), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const RefObject*>(scene_d), out);
 }
 
 void launch_tonemap(const float* film, uint32_t npix, float iters, uint32_t* ldr, hipStream_t stream) {
