@@ -68,6 +68,19 @@ __device__ __forceinline__ T load_uniform(const T* p) {
   return out;
 }
 
+// Where a loop body takes an object's wave-uniform matrix from.
+//   XF_SGPR: scalar loads (s_load_dwordx4/x8 through the constant address space) -> the entries are SGPR operands of the
+//            VALU instructions. No VGPRs, but a v_mul_f32 / v_add_f32 / v_fma_f32 with an SGPR source issues in 4.25 cycles
+//            per wavefront instead of 2.5 (tools/micro/issue_rate.hip) -- and each entry feeds two of them per trip;
+//   XF_LDS : broadcast ds_read_b128 from the kernel's LDS copy of the DevXform table -> the entries are VGPRs (12 per
+//            object while it is being tested), the arithmetic runs at the full rate and no scalar-cache wait precedes it.
+enum XfSource { XF_SGPR = 0, XF_LDS = 1 };
+template <int SRC>
+__device__ __forceinline__ Affine object_mi(const DevXform* __restrict__ xf, const DevXform* __restrict__ xl, uint32_t k) {
+  if (SRC == XF_LDS) return xl[k].mi;
+  return load_uniform(&xf[k].mi);
+}
+
 __device__ __forceinline__ Hit no_hit() {   // Ray.inl:30  Hit() : m_t(-1), m_id(-1), vec3s zero
   Hit h; h.t = -1.0f; h.id = -1; h.pos = splat3(0.0f); h.nor = splat3(0.0f); return h;
 }
@@ -335,12 +348,12 @@ __device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform*
 
 // K planes at once. Ray.inl:142-158: t = -o.y/d.y, hit iff |x|,|z| < 0.5 (strict); the normal is
 // always object +y -> DevXform::nor_y. Only t > 0 competes (Ray.inl:72).
-template <int K, uint32_t P>
+template <int K, uint32_t P, int SRC>
 __device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
                                        const DevXform* __restrict__ xg, uint32_t first, Held& h) {
   Ray r[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space<P>(ray, load_uniform(&xf[first + k].mi), live);    // Ray.inl:88
+  for (int k = 0; k < K; ++k) r[k] = to_object_space<P>(ray, object_mi<SRC>(xf, xg, first + k), live);    // Ray.inl:88
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const float tp = -r[k].pos.y / r[k].dir.y;
@@ -353,12 +366,12 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, c
 
 // K spheres at once. Ray.inl:103-118: radius 0.5, geometric method, normal = normalize(pos),
 // then Ray.inl:62 normalize(M * (n, 0)) -- both only for a held candidate (flush_held).
-template <int K, uint32_t P>
+template <int K, uint32_t P, int SRC>
 __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
                                         const DevXform* __restrict__ xg, uint32_t first, Held& h, uint32_t mesh_first) {
   Ray r[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space<P>(ray, load_uniform(&xf[first + k].mi), live);
+  for (int k = 0; k < K; ++k) r[k] = to_object_space<P>(ray, object_mi<SRC>(xf, xg, first + k), live);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const f3 l = -r[k].pos;
@@ -375,26 +388,26 @@ __device__ __forceinline__ void spheres(Closest& c, const Ray& ray, lmask live, 
 }
 
 // objects [lo, hi) of the group, two per trip
-template <uint32_t P>
+template <uint32_t P, int SRC>
 __device__ __forceinline__ void planes_range(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
                                              const DevXform* __restrict__ xg, uint32_t lo, uint32_t hi, Held& h) {
   uint32_t i = lo;
-  for (; i + 2 <= hi; i += 2) planes<2, P>(c, ray, live, xf, xg, i, h);
-  if (i < hi) planes<1, P>(c, ray, live, xf, xg, i, h);
+  for (; i + 2 <= hi; i += 2) planes<2, P, SRC>(c, ray, live, xf, xg, i, h);
+  if (i < hi) planes<1, P, SRC>(c, ray, live, xf, xg, i, h);
 }
-template <uint32_t P>
+template <uint32_t P, int SRC>
 __device__ __forceinline__ void spheres_range(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
                                               const DevXform* __restrict__ xg, uint32_t lo, uint32_t hi, Held& h, uint32_t mesh_first) {
   uint32_t i = lo;
-  for (; i + 2 <= hi; i += 2) spheres<2, P>(c, ray, live, xf, xg, i, h, mesh_first);
-  if (i < hi) spheres<1, P>(c, ray, live, xf, xg, i, h, mesh_first);
+  for (; i + 2 <= hi; i += 2) spheres<2, P, SRC>(c, ray, live, xf, xg, i, h, mesh_first);
+  if (i < hi) spheres<1, P, SRC>(c, ray, live, xf, xg, i, h, mesh_first);
 }
 
 // Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
 // -x,+x,-y,+y,-z,else +z, taken from the per-object table of world normals.
-template <uint32_t P>
-__device__ __forceinline__ void cube(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g, const DevCubeExtra& ex_g) {
-  const DevXform xf = load_uniform(&xf_g);
+template <uint32_t P, int SRC>
+__device__ __forceinline__ void cube(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g, const DevXform& xf_l, const DevCubeExtra& ex_g) {
+  const DevXform xf = SRC == XF_LDS ? xf_l : load_uniform(&xf_g);
   const DevCubeExtra ex = load_uniform(&ex_g);
   const Ray r = to_object_space<P>(ray, xf.mi, live);
   float tNear, tFar;
@@ -416,12 +429,13 @@ __device__ __forceinline__ void cube(Closest& c, const Ray& ray, lmask live, con
 // (t, face) key of this ray slot: the winning face is then evaluated once more for its normal
 // (same arithmetic, same t).
 // `xg`, `h`, `k`, `mesh_first`: the spheres' group of held candidates (the mesh is object number k of that table).
+template <int SRC>
 __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g,
                                      const DevMeshExtra& ex_g, const DevScene& sc, uint32_t slot, uint32_t& tri_tests,
                                      const DevXform* __restrict__ xg, Held& h, uint32_t k, uint32_t mesh_first) {
-  const DevXform xf = load_uniform(&xf_g);
+  const Affine mi = SRC == XF_LDS ? xg[k].mi : load_uniform(&xf_g.mi);
   const DevMeshExtra ex = load_uniform(&ex_g);
-  const Ray r = to_object_space(ray, xf.mi, live);
+  const Ray r = to_object_space(ray, mi, live);
   float tNear, tFar;
   const lmask pass_m = slab(r, ex.bmin, ex.bmax, tNear, tFar, live);
   const bool pass = lane_of(pass_m);
@@ -456,6 +470,8 @@ __device__ __forceinline__ void mesh(Closest& c, const Ray& ray, lmask live, con
 // `slot`: this ray's row in the key table of the big-mesh passes (unused while sc.mesh_keys is null).
 // `gather`: where the per-lane matrix gathers of the held candidates read the DevXform table from -- a copy
 // of sc.xf in LDS when the kernel made one (k_queue), else sc.xf itself. Never null.
+// SRC: XF_LDS when `gather` is such a copy in LDS and the object matrices shall be read from it as well (XfSource).
+template <int SRC = XF_SGPR>
 __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const DevScene& sc, uint32_t& tri_tests, uint32_t slot,
                                            const DevXform* __restrict__ gather) {
   const lmask live = __ballot(live_lane);
@@ -469,27 +485,27 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const
   // every object through the full product.
   const bool sparse = (live & ~coords_ok(ray.pos, ray.pos + ray.dir)) == 0ull;
   TRC_MARK("planes");
-  planes_range<XP_FULL>(c, ray, live, xf, xg, 0u, sparse ? sc.plane_end[XP_FULL] : sc.n_plane, h);
+  planes_range<XP_FULL, SRC>(c, ray, live, xf, xg, 0u, sparse ? sc.plane_end[XP_FULL] : sc.n_plane, h);
   if (sparse) {
-    planes_range<XP_DIAG>(c, ray, live, xf, xg, sc.plane_end[XP_FULL], sc.plane_end[XP_DIAG], h);
-    planes_range<XP_BLOCK_X>(c, ray, live, xf, xg, sc.plane_end[XP_DIAG], sc.plane_end[XP_BLOCK_X], h);
-    planes_range<XP_BLOCK_Y>(c, ray, live, xf, xg, sc.plane_end[XP_BLOCK_X], sc.plane_end[XP_BLOCK_Y], h);
-    planes_range<XP_BLOCK_Z>(c, ray, live, xf, xg, sc.plane_end[XP_BLOCK_Y], sc.n_plane, h);
+    planes_range<XP_DIAG, SRC>(c, ray, live, xf, xg, sc.plane_end[XP_FULL], sc.plane_end[XP_DIAG], h);
+    planes_range<XP_BLOCK_X, SRC>(c, ray, live, xf, xg, sc.plane_end[XP_DIAG], sc.plane_end[XP_BLOCK_X], h);
+    planes_range<XP_BLOCK_Y, SRC>(c, ray, live, xf, xg, sc.plane_end[XP_BLOCK_X], sc.plane_end[XP_BLOCK_Y], h);
+    planes_range<XP_BLOCK_Z, SRC>(c, ray, live, xf, xg, sc.plane_end[XP_BLOCK_Y], sc.n_plane, h);
   }
   flush_held<false>(c, ray, xg, h);
   xf += sc.n_plane; xg += sc.n_plane;
   TRC_MARK("spheres");
   const uint32_t mesh_first = sc.n_sphere + sc.n_cube;          // numbering of the spheres' group: [spheres | cubes | meshes]
-  spheres_range<XP_FULL>(c, ray, live, xf, xg, 0u, sparse ? sc.sphere_full : sc.n_sphere, h, mesh_first);
-  if (sparse) spheres_range<XP_DIAG>(c, ray, live, xf, xg, sc.sphere_full, sc.n_sphere, h, mesh_first);
+  spheres_range<XP_FULL, SRC>(c, ray, live, xf, xg, 0u, sparse ? sc.sphere_full : sc.n_sphere, h, mesh_first);
+  if (sparse) spheres_range<XP_DIAG, SRC>(c, ray, live, xf, xg, sc.sphere_full, sc.n_sphere, h, mesh_first);
   xf += sc.n_sphere;
   TRC_MARK("cubes");
   const uint32_t cube_full = sparse ? sc.cube_full : sc.n_cube;
-  for (i = 0; i < cube_full; ++i) cube<XP_FULL>(c, ray, live, xf[i], sc.cubes[i]);
-  for (; i < sc.n_cube; ++i) cube<XP_DIAG>(c, ray, live, xf[i], sc.cubes[i]);
+  for (i = 0; i < cube_full; ++i) cube<XP_FULL, SRC>(c, ray, live, xf[i], xg[sc.n_sphere + i], sc.cubes[i]);
+  for (; i < sc.n_cube; ++i) cube<XP_DIAG, SRC>(c, ray, live, xf[i], xg[sc.n_sphere + i], sc.cubes[i]);
   xf += sc.n_cube;
   TRC_MARK("meshes");
-  for (i = 0; i < sc.n_mesh; ++i) mesh(c, ray, live, xf[i], sc.meshes[i], sc, slot, tri_tests, xg, h, mesh_first + i, mesh_first);
+  for (i = 0; i < sc.n_mesh; ++i) mesh<SRC>(c, ray, live, xf[i], sc.meshes[i], sc, slot, tri_tests, xg, h, mesh_first + i, mesh_first);
   flush_held<true>(c, ray, xg, h, mesh_first);                   // spheres and meshes
   TRC_MARK("closest_done");
   Hit out; out.t = c.t; out.id = c.id; out.pos = c.pos; out.nor = c.nor;

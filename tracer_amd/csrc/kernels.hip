@@ -120,11 +120,15 @@ enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE =
 __device__ __forceinline__ int bounce_step(const FrameParams& fp_in, bool live, uint32_t pixel, uint32_t iter, int depth,
                                            Ray& ray, f3& col, uint32_t& tri_tests, uint32_t slot = 0u,
                                            const DevXform* __restrict__ gather = nullptr, bool gather_given = false,
-                                           bool fp_is_arg0 = false) {
+                                           bool fp_is_arg0 = false, bool xf_in_lds = false) {
   DevScene sc_again;
   if (fp_is_arg0) sc_again = load_uniform(&kernarg_params()->sc);
   const DevScene& sc = fp_is_arg0 ? sc_again : fp_in.sc;
-  Hit hit = closest_hit(ray, live, sc, tri_tests, slot, gather_given ? gather : sc.xf);
+#ifndef TRC_XF_LDS
+#define TRC_XF_LDS 1      // object matrices from the LDS copy of the DevXform table where the kernel made one (intersect.h: XfSource)
+#endif
+  Hit hit = (TRC_XF_LDS && xf_in_lds) ? closest_hit<XF_LDS>(ray, live, sc, tri_tests, slot, gather)
+                                      : closest_hit<XF_SGPR>(ray, live, sc, tri_tests, slot, gather_given ? gather : sc.xf);
   if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
   FrameParams again;
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(kBlock, COMPACT ? 6 : 5) void k_bounce(FrameParams 
     ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
     col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
   }
-  const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true)
+  const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true, false, true)
                              : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i);
   const bool cont = (res == STEP_CONTINUE);
   if (res == STEP_LIGHT) {                                            // the only non-black ending
@@ -703,6 +707,10 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
     for (uint32_t i = threadIdx.x; i < n_dw; i += kBlock) ((uint32_t*)s_xf)[i] = ((const uint32_t*)fp.sc.xf)[i];
     __syncthreads();
   }
+#ifdef TRC_LDS_PAD          // occupancy experiments: extra LDS so that fewer workgroups fit a CU
+  __shared__ uint32_t s_pad[TRC_LDS_PAD];
+  if (qa.total == 0xFFFFFFFFu) s_pad[threadIdx.x] = 1u;
+#endif
   const unsigned lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: task ids this wave has reserved
@@ -771,7 +779,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
       ring_count -= taken;
     }
     if (__ballot(have) == 0ull) break;
-    const int res = LDS_GATHER ? bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, s_xf, true, true)
+    const int res = LDS_GATHER ? bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, s_xf, true, true, true)
                                : bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, fp.sc.xf, true, true);
     TRC_MARK("bounce_done");
     if (res == STEP_CONTINUE) {
@@ -949,7 +957,10 @@ void launch_queue(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stri
   const size_t paths = (size_t)fp.ntile * n_iters;
   (void)hipMemsetAsync(next_task, 0, sizeof(uint32_t), stream);       // (k_queue writes every sample of `stage`)
   unsigned blocks = (unsigned)((paths + kBlock - 1) / kBlock);
-  resident_blocks = resident_blocks / 4u * TRC_QUEUE_WAVES;     // CUs x waves per SIMD (a block = 1 wave per SIMD)
+#ifndef TRC_QUEUE_BLOCKS_PER_CU
+#define TRC_QUEUE_BLOCKS_PER_CU TRC_QUEUE_WAVES
+#endif
+  resident_blocks = resident_blocks / 4u * TRC_QUEUE_BLOCKS_PER_CU;     // CUs x waves per SIMD (a block = 1 wave per SIMD)
   if (blocks > resident_blocks) blocks = resident_blocks;
   const bool lds_gather = gather_records(fp.sc) <= kGatherMax;
   // a small call (an interactive frame: one iteration) is spread over all resident wavefronts: about four
