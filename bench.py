@@ -11,13 +11,20 @@ One "step" = one full 300-iteration render of the 512x512 Cornell box per GPU, i
 camera) resident on the device. For N > 1 (launched by torch.distributed.run, one rank per
 GPU) rank r renders iterations r+1, r+1+N, ... (300 of them: sample-index partition, weak
 scaling) and every step ends with ONE sum-reduce of the film buffers to rank 0 over RCCL,
-followed by the display transform on rank 0 -- the only exchange the path has.
+followed by the display transform on rank 0 -- the only exchange the path has
+(tracer_amd.multi.render_partitioned, the product's own multi-GPU entry).
 
-Rank 0 prints one JSON line. Only the `cpu_baseline` leg touches oracle/.
+Rank 0 prints one JSON line. Beside the contract's fields it carries
+  roofline        the dominant kernel (k_queue) against the FP32 vector peak and against the measured VALU issue ceiling
+  cpu_baseline    the CPU oracle on the host cores (bounded sample)                              [N == 1]
+  extra_configs   short runs of BASELINE.json configs[2], [3], [4] and of the compacted pipeline [N == 1]
+  config4_strong  configs[3]'s shape, 3840x2160, a fixed number of samples split over the N GPUs (strong scaling)
+Only the `cpu_baseline` leg touches oracle/.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,57 +39,54 @@ SEED = 1
 # scene (9 object tests / segment, brute-force 20-triangle mesh behind an AABB).
 FLOP_PER_SEGMENT = 880.0
 FLOP_PER_PATH = 118.0          # ray generation (~103) + accumulate (~15)
+FLOP_PER_TRI_TEST = 74.0       # one full Moeller-Trumbore test, Ray.inl:189-226 (configs[4])
 BYTES_PER_SEGMENT_REF = 108.0  # reference buffer layout, SURVEY.md 8(d)
-PEAK_FP32_TFLOPS = 157.3       # MI355X FP32 vector peak (packed FMA), MI355X_MICROARCH.md
-PEAK_FP32_UNFUSED_TFLOPS = 65.5  # measured (tools/micro/inst_cost.hip): v_mul_f32 / v_add_f32 issue every ~2.4
-                                 # cycles per wave64 per SIMD at 8 waves -> 64 * 1024 SIMDs * 2.4 GHz / 2.4
+PEAK_FP32_TFLOPS = 157.3       # MI355X FP32 vector peak: v_pk_fma_f32, packed AND fused (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-N_SIMD = 1024                    # 256 CUs x 4
-VALU_ISSUE_CYCLES = 2.17         # measured (tools/micro/clock_probe.hip): shader-clock cycles one SIMD needs per
-                                 # wave64 v_mul_f32 / v_add_f32, the cheapest VALU class (v_fma_f32, v_cmp: ~4)
+N_SIMD = 1024                  # 256 CUs x 4
+# ONE issue-cost constant (tools/micro/issue_rate.hip, bank.hip, placement.hip on MI355X): a SIMD accepts one wave64
+# v_add_f32 / v_mul_f32 / v_fma_f32 every 2.5 shader cycles from two or more resident waves (5.0 from one wave alone),
+# whatever the register banks. The numerical contract (-ffp-contract=off) allows no fusing, so the ceiling of this path
+# is one add-or-multiply per lane per 2.5 cycles.
+VALU_ISSUE_CYCLES = 2.5
+C4_W, C4_H, C4_TOTAL_ITERS = 3840, 2160, 512      # config4_strong: an eighth of configs[3]'s 4096 samples per pixel
+
+
+def latest_profile(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", pattern)))
+    return files[-1] if files else None
 
 
 def measured_valu_mix():
-    """VALU wave-instructions per 64 live segments of k_queue on this workload, from the latest committed
-    rocprofv3 PMC pass (tools/pmc_fused.sh -> profiles/*_pmc_k_queue.json: SQ_INSTS_VALU / segments * 64)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(HERE, "profiles", "*_pmc_k_queue.json")))
-    if not files:
-        return None, None
+    """(VALU wave-instructions per 64 live segments, live segments of the profiled launch, file) of k_queue from the
+    latest committed rocprofv3 PMC pass (tools/pmc_fused.sh -> profiles/*_pmc_k_queue.json)."""
+    f = latest_profile("*_pmc_k_queue.json")
+    if not f:
+        return None, None, None
     try:
-        d = json.load(open(files[-1]))
-        return float(d["derived"]["valu_insts_per_64_segments"]), os.path.basename(files[-1])
+        d = json.load(open(f))["derived"]
+        return float(d["valu_insts_per_64_segments"]), int(d["live_segments"]), os.path.basename(f)
     except (KeyError, ValueError):
-        return None, None
+        return None, None, None
 
 
-def measured_hbm_traffic():
-    """HBM bytes of one k_queue launch of this workload from the committed rocprofv3 PMC passes
-    (tools/pmc_hbm.sh -> profiles/*_hbm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(HERE, "profiles", "*_hbm.json")))
-    if not files:
+def measured_hbm_traffic(kernel_substr, pattern, whole_call=False):
+    """HBM bytes per launch from the committed PMC passes (tools/pmc_hbm.sh: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE,
+    separate passes). whole_call: every kernel and fill of the call except the display transform."""
+    f = latest_profile(pattern)
+    if not f:
         return None, None
     try:
-        per = json.load(open(files[-1]))["per_kernel"]
-        k = next(v for name, v in per.items() if "k_queue" in name)
-        return int((k["hbm_read_MB_gfx950_corrected_x2"] + k["hbm_write_MB"]) * 1048576), os.path.basename(files[-1])
+        per = json.load(open(f))["per_kernel"]
+        if whole_call:
+            mb = sum(v["hbm_read_MB_gfx950_corrected_x2"] + v["hbm_write_MB"] for k, v in per.items()
+                     if "tonemap" not in k and "copyBuffer" not in k)
+        else:
+            k = next(v for name, v in per.items() if kernel_substr in name)
+            mb = k["hbm_read_MB_gfx950_corrected_x2"] + k["hbm_write_MB"]
+        return int(mb * 1048576), os.path.basename(f)
     except (KeyError, ValueError, StopIteration):
-        return None, None
-
-
-def measured_hbm_traffic_compacted():
-    """HBM bytes of one 300-iteration call of the compacted wavefront pipeline (every kernel and fill of the call)
-    from the committed PMC passes (PIPE=1 tools/pmc_hbm.sh -> profiles/*_compacted_hbm_summary.json)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(HERE, "profiles", "*_compacted_hbm_summary.json")))
-    if not files:
-        return None, None
-    try:
-        per = json.load(open(files[-1]))["per_kernel"]
-        mb = sum(v["hbm_read_MB_gfx950_corrected_x2"] + v["hbm_write_MB"] for k, v in per.items() if "tonemap" not in k and "copyBuffer" not in k)
-        return int(mb * 1048576), os.path.basename(files[-1])
-    except (KeyError, ValueError):
         return None, None
 
 
@@ -95,7 +99,6 @@ def cpu_baseline():
     s = o.scene_create(0)
     cam = o.camera_default(W, H)
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    out = {}
     # single thread: 8 iterations of the 512x512 workload
     t = time.perf_counter()
     r = o.pathtrace(s, W, H, cam, SEED, 1, 8, want_pbo=False, nthreads=1)
@@ -122,18 +125,104 @@ def cpu_baseline():
     return out
 
 
+def unfused_peak_tflops(mhz):
+    return 64 * N_SIMD * mhz * 1e6 / VALU_ISSUE_CYCLES / 1e12
+
+
+def timed_render(tr, cam, seed, iters, reps, pipeline=None):
+    """`reps` calls of `iters` iterations; (min kernel ms, median kernel ms, counters of one call)."""
+    if pipeline is not None:
+        tr.set_pipeline(pipeline)
+    tr.pathtrace(cam, seed, 1, iters); tr.synchronize()           # warm-up (allocations, code load)
+    ms = []
+    for _ in range(reps):
+        tr.pathtrace(cam, seed, 1, iters)
+        ms.append(tr.last_kernel_ms())
+    tr.reset_counters(); tr.pathtrace(cam, seed, 1, iters); cnt = tr.counters()
+    return min(ms), statistics.median(ms), cnt
+
+
+def extra_configs(ta):
+    """Short runs of the other BASELINE.json configurations on one GPU (rank 0, N == 1). Rates are per call, from HIP
+    events on the launch stream; rooflines use the nominal algorithmic costs of SURVEY.md 8(d)."""
+    out = []
+
+    def seg_entry(name, config, w, h, variant, iters, reps, pipeline):
+        sc = ta.Scene(variant)
+        tr = ta.Tracer(w, h)
+        tr.upload_scene(sc.objects_ptr, sc.size)
+        k_min, k_med, cnt = timed_render(tr, ta.camera_default(w, h), SEED, iters, reps, pipeline)
+        seg, paths, mhz = cnt["live_segments"], cnt["paths"], cnt.get("shader_mhz")
+        tf = (seg * FLOP_PER_SEGMENT + paths * FLOP_PER_PATH) / (k_min * 1e-3) / 1e12
+        e = {"name": name, "config": config, "width": w, "height": h, "iterations": iters,
+             "pipeline": {1: "compacted", 3: "work-queue"}[pipeline],
+             "kernel_ms_min": round(k_min, 4), "kernel_ms_median": round(k_med, 4),
+             "value": round(seg / k_min / 1e3, 1), "unit": "Mseg/s", "live_segments": seg,
+             "roofline": {"bound": "valu", "achieved": round(tf, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(tf / PEAK_FP32_TFLOPS, 4), "flop_per_segment": FLOP_PER_SEGMENT}}
+        if mhz:
+            e["roofline"]["frac_unfused_at_clock"] = round(tf / unfused_peak_tflops(mhz), 4)
+        tr.close()
+        return e
+
+    out.append(seg_entry("glass icosahedron + thin lens, 1024x1024", "BASELINE.json configs[2] (64 of its 1024 iterations)",
+                         1024, 1024, 1, 64, 3, ta.PIPE_QUEUE))
+    out.append(seg_entry("cornell 3840x2160", "BASELINE.json configs[3] (20 of its 4096 iterations, one GPU)",
+                         C4_W, C4_H, 0, 20, 3, ta.PIPE_QUEUE))
+    e = seg_entry("cornell 512x512, compacted wavefront pipeline", "BASELINE.json configs[1] through TRC_PIPE_COMPACTED: per-bounce ray "
+                  "state in HBM, ballot compaction (the north_star's HBM evidence)", W, H, 0, ITERS, 5, ta.PIPE_COMPACTED)
+    t_bytes, src = measured_hbm_traffic(None, "*_compacted_hbm_summary.json", whole_call=True)
+    if t_bytes:
+        gbs = t_bytes / (e["kernel_ms_min"] * 1e-3) / 1e9
+        e["hbm"] = {"traffic": t_bytes, "traffic_source": src, "achieved_GBs": round(gbs, 1), "peak_GBs": PEAK_HBM_GBS,
+                    "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
+    out.append(e)
+
+    # configs[4]: one MESH of 1 310 720 faces, 1024x1024, mode 1, every face against every ray that passed the AABB
+    sc = ta.Scene(2, 8)
+    w = h = 1024
+    tr = ta.Tracer(w, h)
+    tr.upload_scene(sc.objects_ptr, sc.size)
+    cam = ta.camera_default(w, h)
+    for accel, label in ((0, "exhaustive loop, bounding-sphere pre-test (default)"), (2, "exhaustive loop, every pair through the exact arithmetic"),
+                         (1, "BVH in front of the same exact test (SURVEY 8f-3, not the configs[4] definition)")):
+        tr.set_mesh_accel(accel)
+        tr.raytrace1(cam); tr.synchronize()
+        ms = []
+        for _ in range(3 if accel != 2 else 2):
+            tr.raytrace1(cam); ms.append(tr.last_render_ms())
+        tr.reset_counters(); tr.raytrace1(cam); cnt = tr.counters()
+        k_min = min(ms)
+        pairs = cnt["tri_tests"]
+        tf = pairs * FLOP_PER_TRI_TEST / (k_min * 1e-3) / 1e12
+        e = {"name": f"icosphere 1 310 720 faces, 1024x1024, mode 1: {label}", "config": "BASELINE.json configs[4]", "mesh_accel": accel,
+             "frame_ms_min": round(k_min, 4), "frame_ms_median": round(statistics.median(ms), 4),
+             "ray_face_pairs": pairs, "value": round(pairs / (k_min * 1e-3) / 1e12, 4), "unit": "T (ray, face) pairs/s"}
+        if accel != 1:
+            e["roofline"] = {"bound": "valu", "kernel": "k_mesh_brute", "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / PEAK_FP32_TFLOPS, 4), "flop_per_pair": FLOP_PER_TRI_TEST,
+                             "note": "algorithmic flop of the reference's full test per pair (SURVEY.md 8d) / frame time; the kernel decides "
+                                     "nearly every pair from a conservative bound or from det and bary.x alone, so achieved can exceed the "
+                                     "arithmetic it actually issues"}
+        out.append(e)
+    tr.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pipeline", type=int, default=3, help="0 wavefront, 1 compacted, 2 fused, 3 work queue (default), 4 auto (= 3 on this scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and config4_strong")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import tracer_amd as ta
+    from tracer_amd import multi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,12 +247,28 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    class _HostReduce:
+        """Rehearsal only (all ranks on one GPU): RCCL refuses two ranks on one device, so the sum goes over gloo
+        through the host. Same interface as torch.distributed for multi.reduce_film."""
+        ReduceOp = dist.ReduceOp
+        is_available = staticmethod(lambda: True)
+        is_initialized = staticmethod(lambda: True)
+        get_world_size = staticmethod(lambda: world)
+
+        @staticmethod
+        def reduce(t, dst=0, op=None):
+            host = t.cpu()
+            dist.reduce(host, dst=dst, op=op)
+            if rank == dst:
+                t.copy_(host)
+
+    reducer = _HostReduce if rehearsal else dist
+
     # scene + camera through the product's own host API (no oracle here)
     scene = ta.Scene(0)
     cam = ta.camera_default(W, H)
     # ONE stream for everything: torch's zero_(), the tracer's launches and the RCCL reduce are then ordered by
-    # the stream itself. (torch's default stream has handle 0, which trc_create takes as "make a private
-    # stream" -- the film sum would not wait for the render.)
+    # the stream itself (render_partitioned would otherwise order them with host-side waits).
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
     assert work_stream.cuda_stream != 0
@@ -173,29 +278,10 @@ def main():
     film = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)   # torch owns the film so RCCL can reduce it
     tr.bind_film(film.data_ptr())
 
-    from tracer_amd import multi
-
-    class _HostReduce:
-        """Rehearsal only (all ranks on one GPU): RCCL refuses two ranks on one device, so the sum goes over gloo
-        through the host. Same interface as torch.distributed for multi.reduce_film."""
-        @staticmethod
-        def is_available(): return True
-        @staticmethod
-        def is_initialized(): return True
-        @staticmethod
-        def get_world_size(): return world
-        ReduceOp = dist.ReduceOp
-        @staticmethod
-        def reduce(t, dst=0, op=None):
-            host = t.cpu()
-            dist.reduce(host, dst=dst, op=op)
-            if rank == dst:
-                t.copy_(host)
-
     def step():
-        # the product's own multi-GPU entry: zero the film, render iterations rank+1, rank+1+world, ... of
-        # ITERS x world, ONE sum-reduce to rank 0, display transform there (tracer_amd/multi.py)
-        multi.render_partitioned(tr, cam, SEED, ITERS * world, film, rank, world, _HostReduce if rehearsal else dist)
+        # zero the film, render iterations rank+1, rank+1+world, ... of ITERS x world, ONE sum-reduce to rank 0,
+        # display transform there
+        multi.render_partitioned(tr, cam, SEED, ITERS * world, film, rank, world, reducer)
 
     def fence():
         if world > 1:
@@ -206,30 +292,31 @@ def main():
         step()
     fence()
     tr.reset_counters()
-    kernel_ms = []
+    kernel_ms, step_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
-        # HIP events recorded on the launch stream around the path kernels of this step
-        # (read after the fence below would only see the last step, so query per step; the
-        # query waits for the kernel, which the next step's film.zero_() would do anyway)
+        # HIP events recorded on the launch stream around the path kernels of this step (the query waits for the
+        # kernels, which the next step's film.zero_() would do anyway)
         kernel_ms.append(tr.last_kernel_ms())
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     fence()
     elapsed = time.perf_counter() - t0
     cnt = tr.counters()
 
-    # Untimed self-check of the multi-GPU path: the reduced film holds world x ITERS samples per pixel, so its
-    # mean per sample must agree with the mean of rank 0's own ITERS samples (a sum that did not wait for a
-    # rank's render, or lost a rank, would not).
+    # Untimed self-check of the multi-GPU path: the reduced film must be the one-rank film of the same ITERS x world
+    # iterations up to float summation order (1e-5 * sqrt(iterations), relative to the film's scale).
     film_check = None
     if world > 1:
         step(); torch.cuda.synchronize()
-        mean_all = float(film.sum().item()) / (3.0 * W * H * ITERS * world) if rank == 0 else 0.0
-        film.zero_(); tr.pathtrace(cam, SEED, rank + 1, ITERS, iter_stride=world); torch.cuda.synchronize()
-        mean_own = float(film.sum().item()) / (3.0 * W * H * ITERS)
         if rank == 0:
-            film_check = {"mean_radiance_all_ranks": round(mean_all, 6), "mean_radiance_rank0": round(mean_own, 6),
-                          "ok": bool(abs(mean_all - mean_own) <= 0.01 * mean_own)}
+            reduced = film.clone()
+            film.zero_(); tr.pathtrace(cam, SEED, 1, ITERS * world); torch.cuda.synchronize()     # all iterations on this one GPU
+            scale = float(film.max().item())
+            err = float((reduced - film).abs().max().item())
+            tol = 1e-5 * (ITERS * world) ** 0.5 * scale
+            film_check = {"max_abs_difference_to_one_rank_film": err, "tolerance_1e-5_sqrt_iters": tol, "ok": bool(err <= tol)}
 
     if world > 1:
         cdev = torch.device("cpu") if rehearsal else dev
@@ -238,9 +325,41 @@ def main():
         elapsed = float(tmax.item())
         seg = torch.tensor([cnt["live_segments"], cnt["paths"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)
-        total_segments, total_paths = float(seg[0].item()), float(seg[1].item())
+        total_segments = float(seg[0].item())
     else:
-        total_segments, total_paths = float(cnt["live_segments"]), float(cnt["paths"])
+        total_segments = float(cnt["live_segments"])
+
+    # configs[3]'s shape with a FIXED total of samples split over the ranks (strong scaling), one film sum-reduce
+    config4 = None
+    if not args.no_extra:
+        sc4 = ta.Scene(0)
+        cam4 = ta.camera_default(C4_W, C4_H)
+        tr4 = ta.Tracer(C4_W, C4_H, device=local_rank, stream=work_stream.cuda_stream)
+        tr4.upload_scene(sc4.objects_ptr, sc4.size)
+        film4 = torch.zeros(C4_W * C4_H * 3, dtype=torch.float32, device=dev)
+        tr4.bind_film(film4.data_ptr())
+        multi.render_partitioned(tr4, cam4, SEED, C4_TOTAL_ITERS, film4, rank, world, reducer)       # warm-up
+        fence()
+        tr4.reset_counters()
+        t4 = time.perf_counter()
+        multi.render_partitioned(tr4, cam4, SEED, C4_TOTAL_ITERS, film4, rank, world, reducer)
+        fence()
+        dt4 = time.perf_counter() - t4
+        c4 = tr4.counters()
+        if world > 1:
+            cdev = torch.device("cpu") if rehearsal else dev
+            v = torch.tensor([dt4], dtype=torch.float64, device=cdev); dist.all_reduce(v, op=dist.ReduceOp.MAX); dt4 = float(v.item())
+            s4 = torch.tensor([c4["live_segments"]], dtype=torch.float64, device=cdev); dist.all_reduce(s4, op=dist.ReduceOp.SUM)
+            seg4 = float(s4.item())
+        else:
+            seg4 = float(c4["live_segments"])
+        config4 = {"workload": f"cornell_box_{C4_W}x{C4_H}_mode2", "total_iterations": C4_TOTAL_ITERS,
+                   "note": "BASELINE.json configs[3] quotes 4096 iterations; this is an eighth of them, split over the GPUs by sample index",
+                   "iterations_per_gpu": multi.rank_iterations(C4_TOTAL_ITERS, rank, world)[2], "n_gpus": world, "scaling": "strong",
+                   "seconds": round(dt4, 4), "value": round(seg4 / dt4 / 1e6, 1), "unit": "Mseg/s",
+                   "film_reduce_bytes": 12 * C4_W * C4_H if world > 1 else 0}
+        tr4.close()
+        del film4
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -261,6 +380,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_min": round(min(step_ms), 4),
+            "ms_per_step_median": round(statistics.median(step_ms), 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -279,52 +400,60 @@ def main():
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "peak_unfused_measured": PEAK_FP32_UNFUSED_TFLOPS,
-                "frac_unfused_measured": round(achieved / PEAK_FP32_UNFUSED_TFLOPS, 4),
-                "peak_unfused_nominal": 39.3,      # 16 lanes/SIMD/clock
-                "frac_unfused_nominal": round(achieved / 39.3, 4),
                 "kernel_ms": round(k_ms, 4),
+                "kernel_ms_min": round(min(kernel_ms), 4),
+                "kernel_ms_median": round(statistics.median(kernel_ms), 4),
                 "flop_per_segment": FLOP_PER_SEGMENT,
                 "flop_per_path": FLOP_PER_PATH,
+                "valu_issue_cycles_per_wave_inst": VALU_ISSUE_CYCLES,
                 "traffic": None,
                 "traffic_source": None,
                 "hbm_algorithmic_GBs": round(seg_per_launch * BYTES_PER_SEGMENT_REF / (k_ms * 1e-3) / 1e9, 2),
                 "hbm_peak_GBs": PEAK_HBM_GBS,
             },
         }
+        rl = out["roofline"]
         if args.pipeline in (3, 4):
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_hbm_traffic()
+            rl["traffic"], rl["traffic_source"] = measured_hbm_traffic("k_queue", "*_hbm.json")
         if args.pipeline == 1:
             # the per-bounce ray state is the point of this pipeline: its HBM rate against the chip's peak
-            t_bytes, src = measured_hbm_traffic_compacted()
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t_bytes, src
+            t_bytes, src = measured_hbm_traffic(None, "*_compacted_hbm_summary.json", whole_call=True)
+            rl["traffic"], rl["traffic_source"] = t_bytes, src
             if t_bytes:
-                out["roofline"]["hbm_achieved_GBs"] = round(t_bytes / (k_ms * 1e-3) / 1e9, 1)
-                out["roofline"]["hbm_frac"] = round(t_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                rl["hbm_achieved_GBs"] = round(t_bytes / (k_ms * 1e-3) / 1e9, 1)
+                rl["hbm_frac"] = round(t_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
         if args.pipeline in (2, 3, 4) and cnt.get("shader_mhz"):
-            # FP32 VALU utilisation (the north_star's figure of merit): issue cycles the kernel's VALU
-            # instructions need at the best rate the SIMD has, over the cycles it ran -- instruction count
-            # from the committed PMC pass, shader clock measured live by the kernel's own wavefronts.
+            # The unfused ceiling at the clock the kernel ran at (its own wavefronts measure it), and the north_star's
+            # figure of merit: VALU issue utilisation = issue cycles the kernel's VALU instructions need at the SIMD's
+            # best rate / the cycles it ran. Instruction count from the committed PMC pass of the same launch
+            # (flagged if that profile's segment count is not this run's), clock and duration live.
             mhz = cnt["shader_mhz"]
-            out["roofline"]["shader_mhz"] = round(mhz, 1)
-            out["roofline"]["peak_unfused_at_clock"] = round(64 * N_SIMD * mhz * 1e6 / VALU_ISSUE_CYCLES / 1e12, 2)
-            out["roofline"]["frac_unfused_at_clock"] = round(achieved / out["roofline"]["peak_unfused_at_clock"], 4)
-            per64, src = measured_valu_mix()
+            rl["shader_mhz"] = round(mhz, 1)
+            rl["peak_unfused_at_clock"] = round(unfused_peak_tflops(mhz), 2)
+            rl["frac_unfused_at_clock"] = round(achieved / rl["peak_unfused_at_clock"], 4)
+            per64, prof_segs, src = measured_valu_mix()
             if per64 and args.pipeline != 2:
                 insts_per_simd = per64 * seg_per_launch / 64.0 / N_SIMD
                 cycles = k_ms * 1e-3 * mhz * 1e6
-                out["roofline"]["valu_insts_per_64_segments"] = per64
-                out["roofline"]["valu_insts_source"] = src
-                out["roofline"]["valu_issue_utilisation"] = round(insts_per_simd * VALU_ISSUE_CYCLES / cycles, 4)
+                rl["valu_insts_per_64_segments"] = round(per64, 1)
+                rl["valu_insts_source"] = src
+                rl["valu_insts_profile_matches_run"] = bool(prof_segs == int(seg_per_launch))
+                rl["valu_issue_utilisation"] = round(insts_per_simd * VALU_ISSUE_CYCLES / cycles, 4)
         if film_check is not None:
             out["film_check"] = film_check
+        if config4 is not None:
+            out["config4_strong"] = config4
         if rehearsal:
             out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
+        tr.close()
+        if world == 1 and not args.no_extra:
+            out["extra_configs"] = extra_configs(ta)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
+    else:
+        tr.close()
 
-    tr.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -30,6 +30,9 @@ def test_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and "rehearsal" in out
     assert out["film_check"]["ok"], out["film_check"]
+    # configs[3]'s shape, a fixed total split over the ranks (strong scaling), through the same product function
+    c4 = out["config4_strong"]
+    assert c4["scaling"] == "strong" and c4["n_gpus"] == 2 and c4["iterations_per_gpu"] * 2 == c4["total_iterations"] and c4["value"] > 0
     # both ranks rendered 300 iterations of 512x512 per step: the whole job's segments are twice one rank's
     per_gpu = out["config"]["live_segments_per_step_per_gpu"]
     assert abs(out["value"] * 1e6 * out["ms_per_step"] * 1e-3 / (2 * per_gpu) - 1.0) < 0.01

@@ -21,5 +21,6 @@ for r in range(reps):
     tr.pathtrace(cam, 1, 1, iters)
     ms = tr.last_kernel_ms()
     c = tr.counters()
-    print(f"pipe {pipe} rep {r}: {ms:.3f} ms, {c['live_segments']} segs, {c['live_segments']/ms/1e3:.1f} Mseg/s, tri_tests {c['tri_tests']}", flush=True)
+    print(f"pipe {pipe} rep {r}: {ms:.3f} ms, {c['live_segments']} segs, {c['live_segments']/ms/1e3:.1f} Mseg/s, tri_tests {c['tri_tests']}, "
+          f"paths {c['paths']}, shader_mhz {c['shader_mhz'] or 0:.1f}", flush=True)
 tr.close()
