@@ -226,3 +226,52 @@ def test_legacy_launchers_notice_a_mesh_swapped_in_place(ta, oracle_c, tmp_path)
     assert L.trc_legacy_release() == 0
     assert np.array_equal(frame(), ref_b)             # and it comes back after a release
     assert L.trc_legacy_release() == 0
+
+
+def test_multi_gpu_c_abi(ta, tmp_path):
+    """include/tracer_multi.h driven by a plain C++ program (tests/cpp/multi_main.cpp; no Python, no torch in that
+    process): one context per listed device, sample-index or row-band partition, one film sum onto GPU 0.
+    On this one-GPU box: G = 1 through a real RCCL communicator and ncclReduce (TRC_MULTI_RCCL_SINGLE=1), and G = 2, 3
+    as several contexts on the one GPU (the library's same-device mode, film[0] += film[r] in order) -- the partition,
+    the per-GPU zeroing and the combine are the code an 8-GPU node runs."""
+    exe = os.path.join(REPO, "tests", "cpp", "bin", "multi_main")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(REPO, "tests", "cpp")], check=True)
+    data = os.path.join(REPO, "tracer_amd", "data")
+    w, h, iters = 160, 96, 7
+    sc = ta.Scene(0)
+    tr = ta.Tracer(w, h)
+    tr.upload_scene(sc.objects_ptr, sc.size)
+    cam = ta.camera_default(w, h)
+    tr.pathtrace(cam, 7, 1, iters)
+    whole, whole_ldr = tr.read_film(), tr.read_ldr()
+
+    def run(devices, by_tile, env=None):
+        out = str(tmp_path / f"m{len(devices)}{by_tile}")
+        r = subprocess.run([exe, data, str(w), str(h), str(iters), str(by_tile), out] + [str(d) for d in devices],
+                           capture_output=True, text=True, timeout=180, env=dict(os.environ, **(env or {})))
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert f"gpus {len(devices)} iterations {iters}" in r.stdout
+        return np.fromfile(out + ".film", np.float32).reshape(-1, 3), np.fromfile(out + ".ldr", np.uint32), r.stdout
+
+    # G = 1: the same film; once plain, once with the RCCL communicator and the (one-rank) ncclReduce in the path
+    for env in (None, {"TRC_MULTI_RCCL_SINGLE": "1"}):
+        film, ldr, _ = run([0], 0, env)
+        assert film.tobytes() == whole.tobytes() and np.array_equal(ldr, whole_ldr)
+    # G = 2, 3 by sample index: exactly the sum of the strided partial films, in rank order; within 1e-5 sqrt(n) of the whole
+    for G in (2, 3):
+        film, ldr, text = run([0] * G, 0)
+        parts = []
+        for r in range(G):
+            tr.reset_film(); tr.pathtrace(cam, 7, r + 1, len(range(r + 1, iters + 1, G)), iter_stride=G); parts.append(tr.read_film())
+        expect = parts[0]
+        for p in parts[1:]:
+            expect = (expect + p).astype(np.float32)
+        assert film.tobytes() == expect.tobytes(), G
+        assert np.abs(film - whole).max() <= 1e-5 * np.sqrt(iters) * whole.max()
+        tr.write_film(expect); tr.tonemap(iters)
+        assert np.array_equal(ldr, tr.read_ldr())
+    # G = 3 by bands of rows: disjoint tiles over zeroed films -> the whole film bit for bit
+    film, ldr, _ = run([0, 0, 0], 1)
+    assert film.tobytes() == whole.tobytes() and np.array_equal(ldr, whole_ldr)
+    tr.close()

@@ -31,6 +31,26 @@ def test_library_exports_every_declared_symbol(product_lib):
         assert getattr(product_lib, name) is not None
 
 
+def test_multi_gpu_library_exports_every_declared_symbol(product_lib):
+    """include/tracer_multi.h -> tracer_amd/libtracer_amd_multi.so (context API + RCCL). Checked from its dynamic symbol
+    table, without loading it: the library brings in the system's RCCL and HIP runtime, which must not be mixed
+    into a process that also holds PyTorch's copies (One HIP runtime per process)."""
+    import subprocess
+    lib = os.path.join(REPO, "tracer_amd", "libtracer_amd_multi.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(REPO, "tracer_amd", "csrc"), "-j8"], check=True, stdout=subprocess.DEVNULL)
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = set(line.split()[-1] for line in out.splitlines() if " T " in line)
+    declared = [s for s in declared_symbols("tracer_multi.h") if s.startswith("trc_multi_")]
+    assert len(declared) == 12, declared
+    assert not [s for s in declared if s not in exported]
+    needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True, check=True).stdout
+    assert "librccl" in needed and "libtracer_amd.so" in needed
+    # and libtracer_amd.so itself stays free of RCCL
+    needed = subprocess.run(["readelf", "-d", os.path.join(REPO, "tracer_amd", "libtracer_amd.so")], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed
+
+
 def test_no_oracle_on_the_product_path():
     """Nothing under tracer_amd/ (library sources or binding) or the C++ host layer may reach into oracle/."""
     bad = []
