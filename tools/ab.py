@@ -56,7 +56,7 @@ def main():
     for name, _ in libs:
         v = res[name]
         print(f"{name:14s} min {min(v):.3f} ms  median {statistics.median(v):.3f} ms  max {max(v):.3f}  ({len(v)} launches, "
-              f"{info[name]['segs'] / min(v) / 1e6:.2f} Gseg/s at the min, clock {info[name]['mhz']:.0f} MHz)", flush=True)
+              f"{info[name]['segs'] / min(v) / 1e6:.2f} Gseg/s at the min, clock {info[name]['mhz'] or 0:.0f} MHz)", flush=True)
 
 
 if __name__ == "__main__":
