@@ -146,6 +146,9 @@ __device__ __forceinline__ int bounce_step(const FrameParams& fp_in, bool live, 
     uint32_t randidx;
     udivmod(pixel + (uint32_t)(int)dot(ray.dir, ray.pos), fp.div_npix, randidx);
     rnd = rand3(fp.seed_lo, fp.seed_hi, randidx, iter, 0u);
+#ifdef TRC_DUP_RNG          // cost-measuring build (tools/pmc_dup.sh)
+    { uint32_t ri = randidx; asm volatile("" : "+v"(ri)); f3 r2 = rand3(fp.seed_lo, fp.seed_hi, ri, iter, 0u); if (r2.x != rnd.x) rnd = r2; }
+#endif
   } else {
     rnd = rand3(fp.seed_lo, fp.seed_hi, pixel, iter, 1u + (uint32_t)depth);
   }

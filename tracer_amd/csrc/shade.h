@@ -59,18 +59,36 @@ TRC_HD f3 refract_pm(f3 I, f3 N, float eta) {
 
 // `inv_ior` = 1.0f / ior, divided once per object at upload: n1 / n2 of Material.inl:100, :104 is 1/ior from
 // outside and ior / 1 = ior from inside.
+TRC_HD f3 bounce_trans(float ior, float inv_ior, f3 rd, f3 nor, f3 randvec) {
+  float n1, n2, eta; f3 nnor;
+  if (dot(rd, nor) < 0.0f) { n1 = 1.0f; n2 = ior; eta = inv_ior; nnor = nor; }     // from outside
+  else                     { n1 = ior; n2 = 1.0f; eta = ior; nnor = -nor; }        // from inside
+  float refl = reflectance(rd, nnor, n1, n2, eta);
+  if (randvec.x < refl) return reflect(rd, nnor);
+  return refract_pm(rd, nnor, eta);
+}
+#if defined(__HIP_DEVICE_COMPILE__) && (defined(TRC_DUP_TRANS) || defined(TRC_DUP_DIFF))
+// cost-measuring builds (tools/pmc_dup.sh): the named branch is evaluated twice, the second time on inputs the
+// optimiser cannot see through, so that the difference in SQ_INSTS_VALU is that branch's dynamic cost
+__device__ __forceinline__ f3 opaque3(f3 v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z)); return v; }
+#endif
 TRC_HD f3 bounce(int mat_type, float ior, float inv_ior, f3 rd, f3 nor, f3 randvec) {
   if (mat_type == REF_DIFF) {
-    return rand_vector_hem(randvec.x, randvec.y, nor);
+    f3 r = rand_vector_hem(randvec.x, randvec.y, nor);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TRC_DUP_DIFF)
+    f3 r2 = rand_vector_hem(opaque3(randvec).x, opaque3(randvec).y, opaque3(nor));
+    if (r2.x != r.x) r = r2;
+#endif
+    return r;
   } else if (mat_type == REF_MIRR) {
     return reflect(rd, nor);
   } else {
-    float n1, n2, eta; f3 nnor;
-    if (dot(rd, nor) < 0.0f) { n1 = 1.0f; n2 = ior; eta = inv_ior; nnor = nor; }     // from outside
-    else                     { n1 = ior; n2 = 1.0f; eta = ior; nnor = -nor; }        // from inside
-    float refl = reflectance(rd, nnor, n1, n2, eta);
-    if (randvec.x < refl) return reflect(rd, nnor);
-    return refract_pm(rd, nnor, eta);
+    f3 r = bounce_trans(ior, inv_ior, rd, nor, randvec);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TRC_DUP_TRANS)
+    f3 r2 = bounce_trans(ior, inv_ior, opaque3(rd), opaque3(nor), opaque3(randvec));
+    if (r2.x != r.x) r = r2;
+#endif
+    return r;
   }
 }
 
