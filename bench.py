@@ -178,6 +178,23 @@ def extra_configs(ta):
                     "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
     out.append(e)
 
+    # configs[0]'s kernel (mode 1: one closest hit + flat shade per pixel, raytrace.cu:29-62) at 3840x2160, and the same
+    # primary rays as a caller-supplied batch through trc_intersect_rays_device (the picking path, main.cpp:180-208)
+    sc = ta.Scene(0)
+    tr = ta.Tracer(C4_W, C4_H)
+    tr.upload_scene(sc.objects_ptr, sc.size)
+    tr.set_record_hits(False)
+    cam = ta.camera_default(C4_W, C4_H)
+    tr.raytrace1(cam); tr.synchronize()
+    ms = []
+    for _ in range(5):
+        tr.raytrace1(cam); ms.append(tr.last_render_ms())
+    n_rays = C4_W * C4_H
+    out.append({"name": "cornell 3840x2160, mode 1 (primary closest hit + flat shade)", "config": "BASELINE.json configs[0]'s kernel at 4K",
+                "frame_ms_min": round(min(ms), 4), "frame_ms_median": round(statistics.median(ms), 4),
+                "value": round(n_rays / (min(ms) * 1e-3) / 1e9, 3), "unit": "Grays/s"})
+    tr.close()
+
     # configs[4]: one MESH of 1 310 720 faces, 1024x1024, mode 1, every face against every ray that passed the AABB
     sc = ta.Scene(2, 8)
     w = h = 1024
