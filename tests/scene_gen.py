@@ -139,3 +139,53 @@ def offset_mesh_scene(path, obj_path, offset, scale=2.0, lens=0.5):
     with open(path, "w") as f:
         f.write("\n".join(L) + "\n")
     return path
+
+
+def stress_scene(path, seed=1):
+    """Transforms at the edges of what the (ray, object) pre-test of intersect.h accepts (bound.h): tiny and huge
+    objects, objects far from the origin, scale ratios around the conditioning limit of 64 (below it the bounding sphere
+    is used, above it every ray keeps its pair), skew from a rotation between two non-uniform scales, meshes of both
+    kinds; no walls, so rays also leave the scene."""
+    r = np.random.default_rng(seed)
+    L = ["camera fov 40 zoom -30 focal 30 lens 0.3",
+         "mesh box cube", "mesh ball sphere", "mesh wall plane",
+         f"mesh ico obj {os.path.join(DATA, 'icosahedron.obj')}", "mesh ball2 icosphere ico 1"]
+    mats = ["diff", "mirr", "trans"]
+
+    def rotate():
+        ax = r.normal(size=3); ax /= np.linalg.norm(ax)
+        return "  rotate %.2f %.4f %.4f %.4f" % (r.uniform(-180, 180), *ax)
+
+    def finish(k):
+        out = ["  color %.3f %.3f %.3f" % tuple(r.uniform(0.4, 1.0, 3)), "  material " + mats[k % 3]]
+        if mats[k % 3] == "trans":
+            out.append("  ior 1.5")
+        return out
+
+    L += ["object wall", "  scale 60 60 60", "  translate 0 -12 0", "  color 0.8 0.8 0.8"]
+    L += ["object box", "  scale 8 0.5 8", "  translate 0 14 0", "  color 1 1 1", "  emit 3"]
+    kinds = ["ball", "box", "ico", "ball2"]
+    specs = [  # (scale xyz, second scale or None, translate)
+        ((0.004, 0.004, 0.004), None, (0.5, 0.2, 3.0)),            # tiny
+        ((0.02, 0.02, 0.02), None, (-0.3, -0.1, 6.0)),
+        ((9.0, 9.0, 9.0), None, (0.0, -2.0, -14.0)),               # big
+        ((1.0, 1.0, 1.0), None, (2000.0, 900.0, -4000.0)),         # far away (never hit; the pre-test must cope with |c|)
+        ((2.0, 2.0, 2.0), None, (6.0, 3.0, -3.0)),
+        ((6.0, 0.1, 6.0), None, (-5.0, 4.0, -2.0)),                # ratio 60: inside the limit
+        ((7.0, 0.1, 3.0), None, (5.0, -4.0, -1.0)),                # ratio 70: outside, no bound
+        ((0.1, 5.0, 0.1), None, (-6.0, -3.0, 1.0)),                # needle, ratio 50
+        ((3.0, 0.3, 1.0), (1.0, 4.0, 0.5), (0.0, 5.0, 2.0)),       # skew: scale, rotate, scale
+        ((1.5, 1.5, 1.5), (3.0, 0.2, 1.0), (-2.0, 0.0, 4.0)),
+    ]
+    k = 0
+    for sc, sc2, at in specs:
+        for kind in kinds:
+            jitter = r.uniform(-0.8, 0.8, 3) * min(1.0, max(sc))
+            L += ["object " + kind, "  scale %.6g %.6g %.6g" % sc, rotate()]
+            if sc2:
+                L += ["  scale %.6g %.6g %.6g" % sc2, rotate()]
+            L += ["  translate %.6g %.6g %.6g" % tuple(np.array(at) + jitter)] + finish(k)
+            k += 1
+    with open(path, "w") as f:
+        f.write("\n".join(L) + "\n")
+    return path

@@ -19,6 +19,21 @@
 #define TRC_MARK(name)
 #endif
 
+// Diagnostic builds (-DTRC_SECTION=n, tools/section_clocks.sh): the tri_tests counter sums the shader cycles that the
+// wavefronts spend between TRC_SECT_BEGIN(n, ..) and TRC_SECT_END(n, ..) instead of counting triangle tests.
+#ifndef TRC_SECTION
+#define TRC_SECTION 0
+#endif
+#define TRC_SECT_BEGIN(n, acc) do { if (TRC_SECTION == (n)) (acc) -= (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#define TRC_SECT_END(n, acc)   do { if (TRC_SECTION == (n)) (acc) += (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+// Checking builds of the (ray, object) pre-test further down (tests/test_gpu_pairs.py): EVERY pair is tested exactly and carries the pre-test's verdict.
+//   TRC_PAIRS_CHECK == 1: the tri_tests counter counts the pairs that the pre-test called a certain miss and that hit
+//                         their object at t > 0 or passed a mesh's AABB -- must be zero;
+//   TRC_PAIRS_CHECK == 2: it counts the pairs that the pre-test called a certain miss (what the product build skips).
+#ifndef TRC_PAIRS_CHECK
+#define TRC_PAIRS_CHECK 0
+#endif
+
 namespace trc {
 
 // ---- wave64 helpers ---------------------------------------------------------------------------
@@ -206,6 +221,11 @@ constexpr int kMaxWavesPerBlock = 4;
 #define TRC_MESH_SLOTS 64          // mailboxes per wavefront; with fewer than 64, mesh_closest() takes the passing rays in rounds
 #endif
 static_assert(TRC_MESH_SLOTS >= 1 && TRC_MESH_SLOTS <= 64, "TRC_MESH_SLOTS");
+// this wavefront's mailboxes (one array per workgroup, shared by mesh_closest() and the (ray, object) pairs below)
+__device__ __forceinline__ MeshSlot* wave_slots() {
+  __shared__ MeshSlot s_slots[kMaxWavesPerBlock * TRC_MESH_SLOTS];
+  return s_slots + (threadIdx.x >> 6) * TRC_MESH_SLOTS;
+}
 
 // MESH, Ray.inl:160-186: brute force over the object's triangles in face order, strict `<`
 // (lowest face index wins ties, Ray.inl:174). Wave-convergent; `pass` marks the lanes whose
@@ -218,12 +238,11 @@ static_assert(TRC_MESH_SLOTS >= 1 && TRC_MESH_SLOTS <= 64, "TRC_MESH_SLOTS");
 // slot and the ray's own lane collects (t, normal) at the end.
 __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const DevTri* __restrict__ tris,
                                               const DevMeshExtra& ex, f3& bn, uint32_t& tri_tests) {
-  __shared__ MeshSlot s_slots[kMaxWavesPerBlock * TRC_MESH_SLOTS];
   const uint32_t first = ex.tri_first, count = ex.tri_count;
   float best = FLT_MAX;
   bn = splat3(0.0f);
   if (__builtin_expect(mask == 0ull || count == 0u, 0)) return best;
-  if (lane_of(mask)) tri_tests += count;
+  if (TRC_SECTION == 0 && TRC_PAIRS_CHECK == 0 && lane_of(mask)) tri_tests += count;
   const unsigned lane = lane_id();
   const unsigned G = count < 64u ? count : 64u;                  // triangles side by side in one pass
   const unsigned R = ex.rays_per_pass;                           // 64 / G rays side by side
@@ -239,7 +258,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
   // cost model (VALU instructions per wave): pair enumeration ~ ceil(n_pass / R) * n_chunks * 110,
   // ray-per-lane ~ count * 95
   if (__builtin_expect(((n_pass + R - 1u) / R) * n_chunks * 5u <= count * 4u, 1)) {
-    MeshSlot* __restrict__ slots = s_slots + (threadIdx.x >> 6) * TRC_MESH_SLOTS;
+    MeshSlot* __restrict__ slots = wave_slots();
     const unsigned rank = __popcll(round & ((1ull << lane) - 1ull));      // < n_pass <= TRC_MESH_SLOTS
     const unsigned long long KEY_NONE = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // t = FLT_MAX
     if (pass) {
@@ -306,42 +325,26 @@ __device__ __forceinline__ void consider(Closest& c, const Ray& ray, float t, ui
   if (better) { c.mindist = dist; c.t = t; c.id = (int)id; c.pos = wpos; c.nor = wnor; }
 }
 
-// ---- planes and spheres: hold the candidate, transform it once -----------------------------------
-// A ray usually has a positive hit on ONE object of a group (one wall of a box, one of a few
-// spheres), yet Ray.inl:59-64 + :72-74 (world position, world normal, distance, the running
-// comparison) cost as much as the intersection itself. So each lane HOLDS its candidate (t, object
-// space point, object number) while the group is walked, and the world-space half runs once per
-// group with the held object's matrix gathered per lane. If any lane meets a second candidate
-// while holding one, the wave flushes first -- every candidate still goes through consider() in
-// object order, so the result is the one the plain loop produces.
-// Meshes join the spheres' group: a mesh hit is held like a sphere's (with its un-normalised object-space normal
-// `n` in place of normalize(p)), and the group is flushed after the last mesh -- the world-space half of the
-// spheres and of the meshes then runs once per trip instead of once per sphere group and once per mesh.
-struct Held { lmask any; float t; f3 p; uint32_t k; f3 n; };   // any: the lanes holding a candidate (wave mask)
+// ---- planes: hold the candidate, transform it once -------------------------------------------------
+// A ray usually has a positive hit on ONE plane of the scene (one wall of a box), yet Ray.inl:59-64 + :72-74 (world
+// position, distance, the running comparison) cost as much as the intersection itself. So each lane HOLDS its
+// candidate (t, object-space point, object number) while the planes are walked, and the world-space half runs once
+// with the held object's matrix gathered per lane. If any lane meets a second candidate while holding one, the
+// wave flushes first -- every candidate still goes through consider() in object order, so the result is the one
+// the plain loop produces.
+struct Held { lmask any; float t; f3 p; uint32_t k; };   // any: the lanes holding a candidate (wave mask)
 
-// `mesh_first` (SPHERE only): held object numbers from here on are meshes (they follow the spheres and the cubes).
-template <bool SPHERE>
-__device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h,
-                                           uint32_t mesh_first = 0xFFFFFFFFu) {
+__device__ __forceinline__ void flush_held(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h) {
   if (h.any == 0ull) return;
   if (lane_of(h.any)) {
     const DevXform& x = xg[h.k];                                // per-lane gather (a handful of distinct records)
-    const Affine m = x.m;
-    f3 wn = x.nor_y;                                            // planes: object +y (Ray.inl:156, :62)
-    if (SPHERE) {
-      const lmask is_mesh = TRC_UCMP(h.k, mesh_first, I_UGE);
-      const f3 sn = normalize_dev(h.p, h.any & ~is_mesh);       // Ray.inl:116 (a sphere's normal)
-      const f3 on = lane_of(is_mesh) ? h.n : sn;
-      wn = normalize_dev(xform_dir(m, on), h.any);              // Ray.inl:62
-    }
-    consider(c, ray, h.t, x.id, m, h.p, wn);
+    consider(c, ray, h.t, x.id, x.m, h.p, x.nor_y);             // object +y (Ray.inl:156, :62)
   }
   h.any = 0ull;
 }
-template <bool SPHERE>
 __device__ __forceinline__ void hold(Closest& c, const Ray& ray, const DevXform* __restrict__ xg, Held& h,
-                                     lmask cand, float t, f3 p, uint32_t k, uint32_t mesh_first = 0xFFFFFFFFu) {
-  if (__builtin_expect((cand & h.any) != 0ull, 0)) flush_held<SPHERE>(c, ray, xg, h, mesh_first);
+                                     lmask cand, float t, f3 p, uint32_t k) {
+  if (__builtin_expect((cand & h.any) != 0ull, 0)) flush_held(c, ray, xg, h);
   if (lane_of(cand)) { h.t = t; h.p = p; h.k = k; }
   h.any |= cand;
 }
@@ -360,30 +363,7 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, c
     const f3 p = r[k].pos + tp * r[k].dir;
     // Ray.inl:148-149  x < 0.5 && x > -0.5 is |x| < 0.5 for every float (NaN fails both forms); |.| is a source modifier
     const lmask in = TRC_FCMP(__builtin_fabsf(p.x), 0.5f, F_OLT) & TRC_FCMP(__builtin_fabsf(p.z), 0.5f, F_OLT);
-    hold<false>(c, ray, xg, h, live & in & TRC_FCMP(tp, 0.0f, F_OGT), tp, p, first + k);
-  }
-}
-
-// K spheres at once. Ray.inl:103-118: radius 0.5, geometric method, normal = normalize(pos),
-// then Ray.inl:62 normalize(M * (n, 0)) -- both only for a held candidate (flush_held).
-template <int K, uint32_t P, int SRC>
-__device__ __forceinline__ void spheres(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
-                                        const DevXform* __restrict__ xg, uint32_t first, Held& h, uint32_t mesh_first) {
-  Ray r[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) r[k] = to_object_space<P>(ray, object_mi<SRC>(xf, xg, first + k), live);
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const f3 l = -r[k].pos;
-    const float s = dot(l, r[k].dir);
-    const float l2 = dot(l, l);
-    const float m2 = l2 - s * s;
-    const lmask outside = TRC_FCMP(l2, 0.25f, F_OGT);
-    const lmask hit = live & ~(TRC_FCMP(s, 0.0f, F_OLT) & outside) & ~TRC_FCMP(m2, 0.25f, F_OGT);
-    const float q = cr_sqrt(0.25f - m2, hit);
-    const float th = lane_of(outside) ? s - q : s + q;
-    const f3 p = r[k].pos + r[k].dir * th;
-    hold<true>(c, ray, xg, h, hit & TRC_FCMP(th, 0.0f, F_OGT), th, p, first + k, mesh_first);
+    hold(c, ray, xg, h, live & in & TRC_FCMP(tp, 0.0f, F_OGT), tp, p, first + k);
   }
 }
 
@@ -395,75 +375,230 @@ __device__ __forceinline__ void planes_range(Closest& c, const Ray& ray, lmask l
   for (; i + 2 <= hi; i += 2) planes<2, P, SRC>(c, ray, live, xf, xg, i, h);
   if (i < hi) planes<1, P, SRC>(c, ray, live, xf, xg, i, h);
 }
-template <uint32_t P, int SRC>
-__device__ __forceinline__ void spheres_range(Closest& c, const Ray& ray, lmask live, const DevXform* __restrict__ xf,
-                                              const DevXform* __restrict__ xg, uint32_t lo, uint32_t hi, Held& h, uint32_t mesh_first) {
-  uint32_t i = lo;
-  for (; i + 2 <= hi; i += 2) spheres<2, P, SRC>(c, ray, live, xf, xg, i, h, mesh_first);
-  if (i < hi) spheres<1, P, SRC>(c, ray, live, xf, xg, i, h, mesh_first);
+
+// ---- spheres, cubes, meshes: (ray, object) PAIRS ---------------------------------------------------------------------
+// A ray of the Cornell box hits one of these objects on one segment in four, yet walking the object list
+// (Ray.inl:70) makes all 64 lanes run every object's test: the two spheres, the light and the icosahedron's AABB cost
+// ~900 of k_queue's ~1550 VALU instructions per trip. Instead:
+//   1. every ray is tried against every object's world-space BOUNDING SPHERE (bound.h: ~20 instructions; conservative --
+//      it only ever says "certain miss" for a pair the exact test rejects, margins derived there);
+//   2. the surviving (ray, object) pairs are compacted, one per lane (at most 64 per pass, usually one pass);
+//   3. each lane runs the exact test of ITS pair: it fetches the ray from the owning lane (ds_bpermute) and gathers the
+//      object's matrices per lane -- the arithmetic of Ray.inl:50-57 and :103-186 operation for operation, with the
+//      full matrix product (which the sparse products of sparse_xform.h equal bit for bit);
+//   4. the candidates (Ray.inl:59-64 world position / normal, :73 distance) meet in the ray's mailbox: one ds_min_u64 on
+//      (distance bits << 32 | object index) selects what the reference's strict `<` in index order selects
+//      (Ray.inl:72-75: smallest distance, lowest index among equals); the owning lane merges the winner into its Closest.
+// Distances are sums of squares (never negative), so their bit patterns order like their values.
+static_assert(TRC_MESH_SLOTS == 64, "the pair list and the merge use one mailbox per lane");
+
+__device__ __forceinline__ unsigned rank_in(lmask m) {          // number of set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ float pull(int addr, float v) {      // v of the lane addr / 4
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
 }
 
-// Ray.inl:120-140: unit cube slab test; normal = first face within EPS in the order
-// -x,+x,-y,+y,-z,else +z, taken from the per-object table of world normals.
-template <uint32_t P, int SRC>
-__device__ __forceinline__ void cube(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g, const DevXform& xf_l, const DevCubeExtra& ex_g) {
-  const DevXform xf = SRC == XF_LDS ? xf_l : load_uniform(&xf_g);
-  const DevCubeExtra ex = load_uniform(&ex_g);
-  const Ray r = to_object_space<P>(ray, xf.mi, live);
-  float tNear, tFar;
-  const bool hit = lane_of(slab(r, splat3(-0.5f), splat3(0.5f), tNear, tFar, live));
-  const float th = tNear > 0.0f ? tNear : tFar;
-  const f3 p = r.pos + r.dir * th;
-  // six wave-uniform candidates: select from the last test to the first
-  f3 wn = ex.axis_nor[5];
-  if (p.z < -0.5f + kEps) wn = ex.axis_nor[4];
-  if (p.y >  0.5f - kEps) wn = ex.axis_nor[3];
-  if (p.y < -0.5f + kEps) wn = ex.axis_nor[2];
-  if (p.x >  0.5f - kEps) wn = ex.axis_nor[1];
-  if (p.x < -0.5f + kEps) wn = ex.axis_nor[0];
-  consider(c, ray, hit ? th : -1.0f, xf.id, xf.m, p, wn);
-}
-
-// Ray.inl:160-186 (MESH): AABB slab test, then the closest triangle -- from mesh_closest(), or, for a
-// big mesh whose brute-force pass ran before this kernel (kernels.hip: k_mesh_brute), from that pass's
-// (t, face) key of this ray slot: the winning face is then evaluated once more for its normal
-// (same arithmetic, same t).
-// `xg`, `h`, `k`, `mesh_first`: the spheres' group of held candidates (the mesh is object number k of that table).
+// The lanes of `live` whose ray MAY hit object k of the [spheres | cubes | meshes] table (bound.h).
+// l1 = |p|_1 of the ray's origin; unit = the lanes whose direction has |d.d - 1| < 2^-16. Every comparison is false
+// for a NaN, so a ray with a NaN coordinate keeps all its pairs.
 template <int SRC>
-__device__ __forceinline__ void mesh(Closest& c, const Ray& ray, lmask live, const DevXform& xf_g,
-                                     const DevMeshExtra& ex_g, const DevScene& sc, uint32_t slot, uint32_t& tri_tests,
-                                     const DevXform* __restrict__ xg, Held& h, uint32_t k, uint32_t mesh_first) {
-  const Affine mi = SRC == XF_LDS ? xg[k].mi : load_uniform(&xf_g.mi);
-  const DevMeshExtra ex = load_uniform(&ex_g);
-  const Ray r = to_object_space(ray, mi, live);
-  float tNear, tFar;
-  const lmask pass_m = slab(r, ex.bmin, ex.bmax, tNear, tFar, live);
-  const bool pass = lane_of(pass_m);
-  f3 bn;
-  float tb;
-  if (sc.mesh_keys != nullptr && ex.big_slot != kNotBig) {
-    tb = FLT_MAX; bn = splat3(0.0f);
-    if (pass) {
-      tri_tests += ex.tri_count;
-      const unsigned long long key = sc.mesh_keys[(size_t)ex.big_slot * sc.key_stride + slot];
-      if ((uint32_t)(key >> 32) != 0x7f7fffffu) {
-        f3 n;
-        const float t = hit_triangle(r, sc.tris[ex.tri_first + (uint32_t)key], n);
-        if (t > 0.0f) { tb = t; bn = n; }
+__device__ __forceinline__ DevXformTail bound_of(const DevXform* __restrict__ xf, const DevXform* __restrict__ xl, uint32_t k) {
+#ifndef TRC_BOUND_LDS
+#define TRC_BOUND_LDS 1
+#endif
+  return (TRC_BOUND_LDS && SRC == XF_LDS) ? *reinterpret_cast<const DevXformTail*>(&xl[k].nor_y)
+                                          : load_uniform(reinterpret_cast<const DevXformTail*>(&xf[k].nor_y));
+}
+__device__ __forceinline__ lmask may_hit(const Ray& ray, float l1, lmask live, lmask unit, const DevXformTail& b) {
+  const f3 oc = b.nor_y - ray.pos;
+  const float bb = dot(oc, ray.dir), oc2 = dot(oc, oc);
+  const float d2 = oc2 - bb * bb;
+  const float s = kBoundKappa * l1 + b.bound_a;
+  const float th = s * s;
+  const lmask miss = (TRC_FCMP(d2, th, F_OGT) | (TRC_FCMP(bb, 0.0f, F_OLT) & TRC_FCMP(oc2, th, F_OGT))) & TRC_FCMP(oc2, b.bound_far2, F_OLT);
+  return live & ~(miss & unit);
+}
+
+// Pre-test + compaction: appends the surviving pairs of objects k, k + 1, ... to the list in the mailboxes' `pad` words
+// (owning lane | object << 8) while a whole object's survivors still fit (64 entries); advances k and n_pairs.
+// xf / xl: the DevXform table (global / the gather table) at its first non-plane record.
+template <int SRC>
+__device__ __forceinline__ void pairs_collect(const Ray& ray, lmask live, uint32_t n_obj,
+                                              const DevXform* __restrict__ xf, const DevXform* __restrict__ xl,
+                                              uint32_t& k, uint32_t& n_pairs) {
+  if (k >= n_obj) return;
+  MeshSlot* __restrict__ slots = wave_slots();
+  const unsigned lane = lane_id();
+  const float l1 = __builtin_fabsf(ray.pos.x) + __builtin_fabsf(ray.pos.y) + __builtin_fabsf(ray.pos.z);
+  const lmask unit = TRC_FCMP(__builtin_fabsf(dot(ray.dir, ray.dir) - 1.0f), 0x1p-16f, F_OLT);
+  // two objects per trip: both records are read before the first is tested
+  while (k < n_obj) {
+    const bool two = k + 1u < n_obj;
+    const DevXformTail b0 = bound_of<SRC>(xf, xl, k);
+    const DevXformTail b1 = bound_of<SRC>(xf, xl, two ? k + 1u : k);
+    lmask m0 = may_hit(ray, l1, live, unit, b0);
+    lmask m1 = may_hit(ray, l1, live, unit, b1);
+    uint32_t tag0 = lane, tag1 = lane;                              // entry: owning lane | (checking builds) 64 = "certain miss" | object << 8
+    if (TRC_PAIRS_CHECK) { if (!lane_of(m0)) tag0 |= 64u; if (!lane_of(m1)) tag1 |= 64u; m0 = live; m1 = live; }
+    const uint32_t c0 = __popcll(m0), c1 = __popcll(m1);
+    if (n_pairs + c0 > 64u) break;                                  // the list is full: test what it holds first
+    if (lane_of(m0)) slots[n_pairs + rank_in(m0)].pad = tag0 | (k << 8);
+    n_pairs += c0;
+    ++k;
+    if (!two) break;
+    if (n_pairs + c1 > 64u) break;
+    if (lane_of(m1)) slots[n_pairs + rank_in(m1)].pad = tag1 | (k << 8);
+    n_pairs += c1;
+    ++k;
+  }
+}
+
+// What lane j < n_pairs needs to start on pair j: the object and the ray, fetched from the owning lane.
+struct PairFetch { lmask valid; uint32_t k; int src4; Ray w; bool flagged; };
+__device__ __forceinline__ PairFetch pairs_fetch(const Ray& ray, uint32_t n_pairs) {
+  MeshSlot* __restrict__ slots = wave_slots();
+  PairFetch f;
+  f.valid = TRC_UCMP(lane_id(), n_pairs, I_ULT);
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t e = lane_of(f.valid) ? slots[lane_id()].pad : 0u;
+  f.k = e >> 8;
+  f.src4 = (int)((e & 63u) << 2);
+  f.flagged = (e & 64u) != 0u;
+  f.w.pos = mk3(pull(f.src4, ray.pos.x), pull(f.src4, ray.pos.y), pull(f.src4, ray.pos.z));
+  f.w.dir = mk3(pull(f.src4, ray.dir.x), pull(f.src4, ray.dir.y), pull(f.src4, ray.dir.z));
+  return f;
+}
+
+// One pass: every lane tests the pair it fetched. xg: the gather table at its first non-plane record;
+// `slot`: the ray slot of the big-mesh passes (closest_hit()).
+__device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const DevScene& sc,
+                                           const DevXform* __restrict__ xg, uint32_t slot, uint32_t& tri_tests) {
+  MeshSlot* __restrict__ slots = wave_slots();
+  const unsigned lane = lane_id();
+  const lmask valid = f.valid;
+  const uint32_t k = f.k;
+  const int src4 = f.src4;
+  const Ray w = f.w;                                                // the pair's ray (world space)
+  const DevXform& X = xg[k];                                        // per-lane gather
+  const Ray r = to_object_space<XP_FULL>(w, X.mi, valid);           // Ray.inl:88
+  const uint32_t mesh_first = sc.n_sphere + sc.n_cube;
+  const lmask is_s = valid & TRC_UCMP(k, sc.n_sphere, I_ULT);
+  const lmask is_m = valid & TRC_UCMP(k, mesh_first, I_UGE);
+  const lmask is_c = valid & ~(is_s | is_m);
+  float th = -1.0f;                                                 // the pair's object-space t
+  lmask cand = 0ull;                                                // pairs with a hit at t > 0 (Ray.inl:72)
+  if (is_s != 0ull) {
+    // Ray.inl:103-118: radius 0.5, geometric method
+    const f3 l = -r.pos;
+    const float s = dot(l, r.dir);
+    const float l2 = dot(l, l);
+    const float m2 = l2 - s * s;
+    const lmask outside = TRC_FCMP(l2, 0.25f, F_OGT);
+    const lmask hit = is_s & ~(TRC_FCMP(s, 0.0f, F_OLT) & outside) & ~TRC_FCMP(m2, 0.25f, F_OGT);
+    const float q = cr_sqrt(0.25f - m2, hit);
+    th = lane_of(outside) ? s - q : s + q;
+    cand = hit & TRC_FCMP(th, 0.0f, F_OGT);
+  }
+  f3 bn = splat3(0.0f);                                             // MESH: the winning triangle's un-normalised normal
+  lmask box_pass = 0ull;
+  if ((is_c | is_m) != 0ull) {
+    // Ray.inl:121-127 (CUBE, bounds +-0.5) and :161-167 (MESH, the mesh's AABB): one slab test
+    f3 bmin = splat3(-0.5f), bmax = splat3(0.5f);
+    if (lane_of(is_m)) { bmin = X.bmin; bmax = X.bmax; }
+    float tNear, tFar;
+    const lmask pass = slab(r, bmin, bmax, tNear, tFar, is_c | is_m);
+    box_pass = pass;
+    const float thc = tNear > 0.0f ? tNear : tFar;                  // Ray.inl:129
+    if (lane_of(is_c)) th = thc;
+    cand |= pass & is_c & TRC_FCMP(thc, 0.0f, F_OGT);
+    const lmask pass_m = pass & is_m;
+    if (pass_m != 0ull) {
+      TRC_SECT_BEGIN(4, tri_tests);
+      float tb = FLT_MAX;
+      const uint32_t ray_slot = sc.mesh_keys != nullptr ? (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)slot) : 0u;
+      for (uint32_t j = 0; j < sc.n_mesh; ++j) {
+        const lmask mj = pass_m & TRC_UCMP(k, mesh_first + j, I_EQ);
+        if (mj == 0ull) continue;
+        const DevMeshExtra ex = load_uniform(&sc.meshes[j]);
+        if (sc.mesh_keys != nullptr && ex.big_slot != kNotBig) {
+          // a big mesh whose brute-force pass ran before this kernel (kernels.hip: k_mesh_brute): the winning face
+          // is evaluated once more for its normal (same arithmetic, same t)
+          if (lane_of(mj)) {
+            if (TRC_SECTION == 0 && TRC_PAIRS_CHECK == 0) tri_tests += ex.tri_count;
+            const unsigned long long key = sc.mesh_keys[(size_t)ex.big_slot * sc.key_stride + ray_slot];
+            if ((uint32_t)(key >> 32) != 0x7f7fffffu) {
+              f3 n;
+              const float t = hit_triangle(r, sc.tris[ex.tri_first + (uint32_t)key], n);
+              if (t > 0.0f) { tb = t; bn = n; }
+            }
+          }
+        } else {
+          f3 n;
+          const float t = mesh_closest(r, mj, sc.tris, ex, n, tri_tests);
+          if (lane_of(mj)) { tb = t; bn = n; }
+        }
+      }
+      // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero normal forward; the
+      // world-space distance test then rejects it (|o + d * FLT_MAX|^2 overflows to inf) -> explicit miss here.
+      // tb > 0 for every hit (mesh_closest / the key pass keep positive t only).
+      if (lane_of(is_m)) th = tb;
+      cand |= pass_m & TRC_FCMP(tb, FLT_MAX, F_UNE);
+      TRC_SECT_END(4, tri_tests);
+    }
+  }
+  if (TRC_PAIRS_CHECK == 1 && f.flagged && lane_of(cand | (valid & is_m & box_pass))) {
+    ++tri_tests;
+#ifdef TRC_PAIRS_CHECK_PRINT
+    printf("violation: object %u (id %u) ray p=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) th=%.9g cand=%d boxpass=%d centre=(%.9g %.9g %.9g) a=%.9g far2=%.9g\n", k, X.id,
+           w.pos.x, w.pos.y, w.pos.z, w.dir.x, w.dir.y, w.dir.z, th, (int)lane_of(cand), (int)lane_of(box_pass), X.nor_y.x, X.nor_y.y, X.nor_y.z, X.bound_a, X.bound_far2);
+#endif
+  }
+  if (TRC_PAIRS_CHECK == 2 && f.flagged && lane_of(valid)) ++tri_tests;
+  __builtin_amdgcn_wave_barrier();
+  TRC_SECT_BEGIN(5, tri_tests);
+  const unsigned long long KEY_NONE = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;
+  slots[lane].key = KEY_NONE;
+  __builtin_amdgcn_wave_barrier();
+  if (cand != 0ull) {
+    // the hit in world space: Ray.inl:59-64, :73-74
+    const f3 p = r.pos + r.dir * th;
+    const Affine m = X.m;
+    f3 on = bn;                                                     // object-space normal
+    if ((cand & is_s) != 0ull) { const f3 sn = normalize_dev(p, cand & is_s); if (lane_of(is_s)) on = sn; }   // Ray.inl:116
+    if ((cand & is_c) != 0ull && lane_of(is_c)) {
+      // Ray.inl:132-137: the first face within EPS in the order -x, +x, -y, +y, -z, else +z
+      on = mk3(0.0f, 0.0f, 1.0f);
+      if (p.z < -0.5f + kEps) on = mk3(0.0f, 0.0f, -1.0f);
+      if (p.y >  0.5f - kEps) on = mk3(0.0f, 1.0f, 0.0f);
+      if (p.y < -0.5f + kEps) on = mk3(0.0f, -1.0f, 0.0f);
+      if (p.x >  0.5f - kEps) on = mk3(1.0f, 0.0f, 0.0f);
+      if (p.x < -0.5f + kEps) on = mk3(-1.0f, 0.0f, 0.0f);
+    }
+    const f3 wn = normalize_dev(xform_dir(m, on), cand);            // Ray.inl:62
+    const f3 wpos = xform_point(m, p);                              // Ray.inl:61
+    const f3 d = w.pos - wpos;
+    const float dist = dot(d, d);                                   // Ray.inl:73-74
+    // a candidate must beat the initial (FLT_MAX, -1): dist < FLT_MAX (false for a NaN)
+    const bool ok = lane_of(cand & TRC_FCMP(dist, FLT_MAX, F_OLT));
+    const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) | X.id;
+    MeshSlot& o = slots[src4 >> 2];
+    if (ok) atomicMin(&o.key, key);
+    __builtin_amdgcn_wave_barrier();
+    if (ok && o.key == key) { o.px = th; o.py = wpos.x; o.pz = wpos.y; o.dx = wpos.z; o.dy = wn.x; o.dz = wn.y; o.nx = wn.z; }
+    __builtin_amdgcn_wave_barrier();
+    const MeshSlot& mine = slots[lane];
+    const unsigned long long kk = mine.key;
+    if (kk != KEY_NONE) {
+      const float dist_w = __uint_as_float((uint32_t)(kk >> 32));
+      const int id_w = (int)(uint32_t)kk;
+      if ((dist_w < c.mindist) | ((dist_w == c.mindist) & (id_w < c.id))) {      // Ray.inl:75 over (distance, index)
+        c.mindist = dist_w; c.id = id_w; c.t = mine.px;
+        c.pos = mk3(mine.py, mine.pz, mine.dx); c.nor = mk3(mine.dy, mine.dz, mine.nx);
       }
     }
-  } else {
-    tb = mesh_closest(r, pass_m, sc.tris, ex, bn, tri_tests);
   }
-  // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero normal
-  // forward; the world-space distance test then rejects it because |o + d*FLT_MAX|^2 overflows
-  // to inf for any normalised d -> explicit miss here.
-  const lmask hit_m = pass_m & TRC_FCMP(tb, FLT_MAX, F_UNE);
-  const f3 p = r.pos + r.dir * tb;
-  // tb > 0 for every hit (mesh_closest / the key pass keep positive t only): the candidate competes (Ray.inl:72);
-  // its world-space half -- normalize(M * (bn, 0)), M * p, distance -- runs in flush_held()
-  hold<true>(c, ray, xg, h, hit_m, tb, p, k, mesh_first);
-  if (lane_of(hit_m)) h.n = bn;
+  TRC_SECT_END(5, tri_tests);
 }
 
 // Wave-convergent (see the header comment).
@@ -478,13 +613,21 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const
   Closest c; c.mindist = FLT_MAX; c.t = -1.0f; c.id = -1; c.pos = splat3(0.0f); c.nor = splat3(0.0f);
   const DevXform* __restrict__ xf = sc.xf;
   const DevXform* __restrict__ xg = gather;
-  uint32_t i = 0;
-  Held h; h.any = 0ull; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u; h.n = splat3(0.0f);
+  Held h; h.any = 0ull; h.t = -1.0f; h.p = splat3(0.0f); h.k = 0u;
   // Within a type the objects are sorted by the zero pattern of their m_matrixi (scene.h): one straight-line
   // loop body per pattern. A wavefront with a ray that fails the vector-side condition of sparse_xform.h takes
   // every object through the full product.
   const bool sparse = (live & ~coords_ok(ray.pos, ray.pos + ray.dir)) == 0ull;
+  // spheres, cubes, meshes: the pre-test and the fetches of the first pass go ahead of the planes, whose arithmetic
+  // then runs while those LDS round trips are under way
+  const uint32_t n_obj = sc.n_sphere + sc.n_cube + sc.n_mesh;
+  uint32_t pk = 0, n_pairs = 0;
+  TRC_SECT_BEGIN(6, tri_tests); TRC_SECT_BEGIN(2, tri_tests);
+  pairs_collect<SRC>(ray, live, n_obj, xf + sc.n_plane, xg + sc.n_plane, pk, n_pairs);
+  PairFetch pf = pairs_fetch(ray, n_pairs);
+  TRC_SECT_END(2, tri_tests);
   TRC_MARK("planes");
+  TRC_SECT_BEGIN(1, tri_tests);
   planes_range<XP_FULL, SRC>(c, ray, live, xf, xg, 0u, sparse ? sc.plane_end[XP_FULL] : sc.n_plane, h);
   if (sparse) {
     planes_range<XP_DIAG, SRC>(c, ray, live, xf, xg, sc.plane_end[XP_FULL], sc.plane_end[XP_DIAG], h);
@@ -492,22 +635,23 @@ __device__ __forceinline__ Hit closest_hit(const Ray& ray, bool live_lane, const
     planes_range<XP_BLOCK_Y, SRC>(c, ray, live, xf, xg, sc.plane_end[XP_BLOCK_X], sc.plane_end[XP_BLOCK_Y], h);
     planes_range<XP_BLOCK_Z, SRC>(c, ray, live, xf, xg, sc.plane_end[XP_BLOCK_Y], sc.n_plane, h);
   }
-  flush_held<false>(c, ray, xg, h);
+  flush_held(c, ray, xg, h);
+  TRC_SECT_END(1, tri_tests);
   xf += sc.n_plane; xg += sc.n_plane;
   TRC_MARK("spheres");
-  const uint32_t mesh_first = sc.n_sphere + sc.n_cube;          // numbering of the spheres' group: [spheres | cubes | meshes]
-  spheres_range<XP_FULL, SRC>(c, ray, live, xf, xg, 0u, sparse ? sc.sphere_full : sc.n_sphere, h, mesh_first);
-  if (sparse) spheres_range<XP_DIAG, SRC>(c, ray, live, xf, xg, sc.sphere_full, sc.n_sphere, h, mesh_first);
-  xf += sc.n_sphere;
-  TRC_MARK("cubes");
-  const uint32_t cube_full = sparse ? sc.cube_full : sc.n_cube;
-  for (i = 0; i < cube_full; ++i) cube<XP_FULL, SRC>(c, ray, live, xf[i], xg[sc.n_sphere + i], sc.cubes[i]);
-  for (; i < sc.n_cube; ++i) cube<XP_DIAG, SRC>(c, ray, live, xf[i], xg[sc.n_sphere + i], sc.cubes[i]);
-  xf += sc.n_cube;
-  TRC_MARK("meshes");
-  for (i = 0; i < sc.n_mesh; ++i) mesh<SRC>(c, ray, live, xf[i], sc.meshes[i], sc, slot, tri_tests, xg, h, mesh_first + i, mesh_first);
-  flush_held<true>(c, ray, xg, h, mesh_first);                   // spheres and meshes
+  while (n_pairs != 0u) {
+    if (TRC_SECTION == 8 && lane_id() == 0) tri_tests += 64u * n_pairs;      // (diagnostic builds: pairs, passes; x64 like the clock sums)
+    if (TRC_SECTION == 9 && lane_id() == 0) tri_tests += 64u;
+    TRC_SECT_BEGIN(3, tri_tests);
+    pairs_pass(c, pf, sc, xg, slot, tri_tests);
+    TRC_SECT_END(3, tri_tests);
+    n_pairs = 0;
+    if (pk == n_obj) break;                                         // (usually: one pass)
+    pairs_collect<SRC>(ray, live, n_obj, xf, xg, pk, n_pairs);
+    pf = pairs_fetch(ray, n_pairs);
+  }
   TRC_MARK("closest_done");
+  TRC_SECT_END(6, tri_tests);
   Hit out; out.t = c.t; out.id = c.id; out.pos = c.pos; out.nor = c.nor;
   return out;
 }

@@ -4,6 +4,7 @@
 #include "scene.h"
 #include "pmath.h"
 #include "bvh.h"
+#include "bound.h"
 #include <hip/hip_runtime.h>
 
 namespace trc {

@@ -23,7 +23,7 @@ constexpr unsigned kDigestParts = 32;     // workgroups per object of k_scene_di
 #ifndef TRC_GATHER_MAX
 #define TRC_GATHER_MAX 16
 #endif
-constexpr uint32_t kGatherMax = TRC_GATHER_MAX;   // DevXform records k_queue / k_bounce keep in LDS (2 KB)
+constexpr uint32_t kGatherMax = TRC_GATHER_MAX;   // DevXform records k_queue / k_bounce keep in LDS (2.5 KB)
 // the records that held candidates gather per lane (intersect.h: flush_held): planes, spheres and -- through the
 // spheres' group -- meshes; the table is the whole DevXform array
 __host__ __device__ inline uint32_t gather_records(const DevScene& sc) { return sc.n_plane + sc.n_sphere + sc.n_cube + sc.n_mesh; }

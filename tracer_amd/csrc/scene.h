@@ -1,6 +1,7 @@
 // tracer_amd/csrc/scene.h -- scene description as the caller hands it over (the reference's
 // pointer-based AoS) and as the kernels read it (flat, pointer-free, wave-uniform records).
 #pragma once
+#include <cstddef>
 #include "vecmath.h"
 #include "sparse_xform.h"
 
@@ -66,15 +67,22 @@ static_assert(sizeof(DevObject) == 240, "DevObject");
 // chains for the VALU to interleave), and sorting a group by the zero pattern of the matrices lets the
 // loop body leave out the multiplications by exact zeros (sparse_xform.h). The reference's tie rule "lowest object index wins"
 // (strict `<` in index order, Ray.inl:75) is kept by comparing (distance, original index).
-struct alignas(16) DevXform {      // 128 bytes = two s_load_dwordx16
+struct alignas(16) DevXform {      // 160 bytes
   Affine   mi;                     // world -> object (Object::m_matrixi)
   Affine   m;                      // object -> world (Object::m_matrix)
-  f3       nor_y;                  // world normal of object-space +y: what a PLANE hit reports
+  f3       nor_y;                  // PLANE: world normal of object-space +y, what a hit reports; SPHERE / CUBE / MESH: centre of the
+                                   // object's world-space bounding sphere (bound.h)
   uint32_t id;                     // index in the caller's Object[] (Hit::m_id)
   uint32_t mi_pat;                 // XformPattern of mi this object is filed under (sparse_xform.h)
-  uint32_t pad[3];
+  float    bound_a, bound_far2;    // SPHERE / CUBE / MESH: bound.h (radius + the constant part of the slack; far limit)
+  uint32_t pad;
+  f3       bmin; uint32_t pad1;    // MESH: Mesh::m_bmin / m_bmax once more (DevMeshExtra), where a per-lane gather of the record finds them
+  f3       bmax; uint32_t pad2;
 };
-static_assert(sizeof(DevXform) == 128, "DevXform");
+static_assert(sizeof(DevXform) == 160, "DevXform");
+// the 32 bytes behind the matrices, as one record (what the (ray, object) pre-test reads)
+struct alignas(16) DevXformTail { f3 nor_y; uint32_t id; uint32_t mi_pat; float bound_a, bound_far2; uint32_t pad; };
+static_assert(sizeof(DevXformTail) == 32 && offsetof(DevXform, nor_y) == 96 && offsetof(DevXform, bound_far2) == 96 + 24, "DevXformTail");
 struct alignas(16) DevCubeExtra { f3 axis_nor[6]; float pad[2]; };                 // 80 bytes
 struct alignas(16) DevMeshExtra {
   f3 bmin; uint32_t tri_first; f3 bmax; uint32_t tri_count;

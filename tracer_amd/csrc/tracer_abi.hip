@@ -319,6 +319,11 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
       DevXform x; memset(&x, 0, sizeof x);
       x.mi = o.mi; x.m = o.m; x.nor_y = o.axis_nor[3]; x.id = (uint32_t)i;
       x.mi_pat = pat;
+      if (o.mesh_type != REF_PLANE) {                 // the (ray, object) pre-test of intersect.h
+        const ObjectBound b = object_bound(o);
+        x.nor_y = b.centre; x.bound_a = b.a; x.bound_far2 = b.far2;
+        x.bmin = o.bmin; x.bmax = o.bmax;
+      }
       xf.push_back(x);
       if (o.mesh_type == REF_CUBE) {
         DevCubeExtra e; memset(&e, 0, sizeof e);
