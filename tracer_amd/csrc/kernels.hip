@@ -545,8 +545,11 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
 // launch of its own would have had to write first -- 40 bytes per path less written and read again, one launch less
 // per chunk. The launcher zeroes the region counts with a memset node then, and keeps k_raygen only where a big-mesh
 // pass needs the depth-0 rays in memory before this kernel runs.
+#ifndef TRC_BOUNCE_WAVES
+#define TRC_BOUNCE_WAVES 5         // resident waves per SIMD k_bounce is compiled for (6 = 80 VGPRs spills since the (ray, object) pairs)
+#endif
 template <bool COMPACT, bool LDS_GATHER, bool FIRST>
-__global__ __launch_bounds__(kBlock, COMPACT ? 6 : 5) void k_bounce(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
+__global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
                                                   uint32_t n_slots, int depth,
                                                   PathState cur, PathState next,
                                                   const uint32_t* __restrict__ count_in,
