@@ -2,11 +2,10 @@
 // src/Ray.inl in its exact operation order, over the flat scene records of scene.h.
 //
 // closest_hit() is WAVE-CONVERGENT: all 64 lanes of a wavefront must call it together (lanes
-// without a live path pass live = false). That lets the MESH test turn the few lanes whose ray
-// passed the AABB into wave-wide work: the triangles of a 64-triangle chunk are spread over the
-// lanes and each passing ray is broadcast to them in turn (lane <-> triangle instead of
-// lane <-> ray), with the reference's "first index wins" tie rule kept by a wave-wide
-// min + lowest-lane select.
+// without a live path pass live = false). That lets sparse work become wave-wide work: the few (ray, object)
+// pairs that can hit a sphere, cube or mesh are compacted one per lane (lane <-> pair instead of lane <-> ray),
+// and the few rays that pass a mesh's AABB are spread over the lanes as (ray, triangle) pairs; the reference's
+// "closest, lowest index among equals" is kept by a u64 minimum over (distance or t, index) in LDS.
 #pragma once
 #include "scene.h"
 #include "crmath.h"
