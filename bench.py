@@ -63,12 +63,24 @@ def measured_valu_mix():
     latest committed rocprofv3 PMC pass (tools/pmc_fused.sh -> profiles/*_pmc_k_queue.json)."""
     f = latest_profile("*_pmc_k_queue.json")
     if not f:
-        return None, None, None
+        return None, None, None, None
     try:
-        d = json.load(open(f))["derived"]
-        return float(d["valu_insts_per_64_segments"]), int(d["live_segments"]), os.path.basename(f)
+        j = json.load(open(f))
+        d = j["derived"]
+        return float(d["valu_insts_per_64_segments"]), int(d["live_segments"]), os.path.basename(f), j.get("kernel_source_digest")
     except (KeyError, ValueError):
-        return None, None, None
+        return None, None, None, None
+
+
+def kernel_source_digest():
+    """As tools/pmc_summary.py records it: sha256 over tracer_amd/csrc/*.h, *.hip (the sources travel with the library)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(HERE, "tracer_amd", "csrc", "*.h")) + glob.glob(os.path.join(HERE, "tracer_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def measured_hbm_traffic(kernel_substr, pattern, whole_call=False):
@@ -448,13 +460,15 @@ def main():
             rl["shader_mhz"] = round(mhz, 1)
             rl["peak_unfused_at_clock"] = round(unfused_peak_tflops(mhz), 2)
             rl["frac_unfused_at_clock"] = round(achieved / rl["peak_unfused_at_clock"], 4)
-            per64, prof_segs, src = measured_valu_mix()
+            per64, prof_segs, src, prof_digest = measured_valu_mix()
             if per64 and args.pipeline != 2:
                 insts_per_simd = per64 * seg_per_launch / 64.0 / N_SIMD
                 cycles = k_ms * 1e-3 * mhz * 1e6
                 rl["valu_insts_per_64_segments"] = round(per64, 1)
                 rl["valu_insts_source"] = src
-                rl["valu_insts_profile_matches_run"] = bool(prof_segs == int(seg_per_launch))
+                # the profile must be of this workload (segment count) and of these kernel sources (digest recorded by
+                # tools/pmc_summary.py); otherwise the utilisation below mixes two kernels -- flagged, not hidden
+                rl["valu_insts_profile_matches_run"] = bool(prof_segs == int(seg_per_launch) and prof_digest == kernel_source_digest())
                 rl["valu_issue_utilisation"] = round(insts_per_simd * VALU_ISSUE_CYCLES / cycles, 4)
         if film_check is not None:
             out["film_check"] = film_check

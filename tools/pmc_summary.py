@@ -44,7 +44,17 @@ d = {"live_segments": segs, "paths": paths,
      "VALUBusy_formula_saturates_at_pct": 100 * 4 / VALU_ISSUE_FLOOR,
      "valu_lane_utilisation_pct": 100 * c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64),
      "wave_occupancy_mean_waves_per_simd": c["SQ_WAVE_CYCLES"] * 4 / (cyc * N_SIMD) if "SQ_WAVE_CYCLES" in c else None}
-json.dump({"kernel": "trc::" + kname, "tag": tag,
+def kernel_source_digest():
+    """sha256 over the kernel sources (tracer_amd/csrc/*.h, *.hip): bench.py flags a profile taken from other sources."""
+    import glob, hashlib, os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(here, "tracer_amd", "csrc", "*.h")) + glob.glob(os.path.join(here, "tracer_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+json.dump({"kernel": "trc::" + kname, "tag": tag, "kernel_source_digest": kernel_source_digest(),
            "workload": "cornell 512x512 mode 2, 300 iterations, one launch",
            "command": f"tools/pmc_fused.sh {tag} (two rocprofv3 --pmc passes of: python3 tools/prof_run.py {pipe} 1)",
            "units": {"SQ_ACTIVE_INST_VALU": "quad-cycles (4 shader cycles), summed over SIMDs", "SQ_WAVE_CYCLES": "quad-cycles",
