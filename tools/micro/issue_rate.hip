@@ -13,7 +13,7 @@
 #define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 
 enum { ADD, MUL, ADDMUL, FMA3, FMA_S, MUL_S, MIN, MAX3, MOV, CNDMASK, CMP_VCC, CMP_SGPR, CMP_CND, RCP, RSQ, SQRT, MULLO, MULHI, XOR, ADDU, PKMUL, PKFMA,
-       FMA_ADD_MIX, TRANS_MIX, MUL_INLINE, MUL_LITERAL, ADD_E64_NEG, MUL_ABS, FMA_INLINE, CND_SGPRMASK, CND_VCC_FED, READLANE, READFIRST, AND, LSHL, CVT_F32_U32, RNDNE, MAD_U32_U24, BFE, MBCNT, MAX, MIN3, CMP_CLASS, CMP_U32, SUBREV, FMAAK, MIX_SGPR, MIX_CMP, MIX_MIN, MIX_MULLO, MIX_CMP_CND, MIX_SGPR2, NCLASS };
+       FMA_ADD_MIX, TRANS_MIX, MUL_INLINE, MUL_LITERAL, ADD_E64_NEG, MUL_ABS, FMA_INLINE, CND_SGPRMASK, CND_VCC_FED, READLANE, READFIRST, AND, LSHL, CVT_F32_U32, RNDNE, MAD_U32_U24, BFE, MBCNT, MAX, MIN3, CMP_CLASS, CMP_U32, SUBREV, FMAAK, MIX_SGPR, MIX_CMP, MIX_MIN, MIX_MULLO, MIX_CMP_CND, MIX_SGPR2, MIX_PK1, MIX_PK3, PKADD, MIX_PKADD1, MIX_PK_2OF3, NCLASS };
 static const char* NAMES[] = {"v_add_f32", "v_mul_f32", "v_add_f32 / v_mul_f32 alternating", "v_fma_f32 (3 vgpr)", "v_fma_f32 (sgpr operand)",
   "v_mul_f32 (sgpr operand)", "v_min_f32", "v_max3_f32", "v_mov_b32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 -> vcc", "v_cmp_lt_f32 -> sgpr pair",
   "v_cmp_lt_f32 vcc + v_cndmask (pair = 2 inst)", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_xor_b32", "v_add_u32",
@@ -23,7 +23,9 @@ static const char* NAMES[] = {"v_add_f32", "v_mul_f32", "v_add_f32 / v_mul_f32 a
   "v_cvt_f32_u32", "v_rndne_f32", "v_mad_u32_u24", "v_bfe_u32", "v_mbcnt_lo_u32_b32", "v_max_f32", "v_min3_f32", "v_cmp_class_f32 -> sgpr", "v_cmp_lt_u32 -> sgpr",
   "v_subrev_f32", "v_fmaak_f32 (literal addend)",
   "3 v_mul_f32 + 1 v_mul_f32 sgpr (4 inst)", "3 v_mul_f32 + 1 v_cmp -> sgpr (4 inst)", "3 v_mul_f32 + 1 v_min_f32 (4 inst)", "3 v_mul_f32 + 1 v_mul_lo_u32 (4 inst)",
-  "2 v_mul_f32 + v_cmp vcc + v_cndmask vcc (4 inst)", "1 v_mul_f32 + 1 v_mul_f32 sgpr (2 inst)"};
+  "2 v_mul_f32 + v_cmp vcc + v_cndmask vcc (4 inst)", "1 v_mul_f32 + 1 v_mul_f32 sgpr (2 inst)",
+  "1 v_mul_f32 + 1 v_pk_mul_f32 (2 inst)", "3 v_mul_f32 + 1 v_pk_mul_f32 (4 inst)", "v_pk_add_f32", "1 v_add_f32 + 1 v_pk_add_f32 (2 inst)",
+  "1 v_mul_f32 + 2 v_pk_mul_f32 (3 inst)"};
 
 template <int C>
 __global__ __launch_bounds__(256) void k(unsigned long long* span, unsigned long long* ref, float* out, int iters, float a, float b) {
@@ -239,6 +241,24 @@ __global__ __launch_bounds__(256) void k(unsigned long long* span, unsigned long
         M(0) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x[1]) : "s"(sa)); M(2) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x[3]) : "s"(sa));
         M(4) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x[5]) : "s"(sa)); M(6) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x[7]) : "s"(sa));
 #undef M
+      } else if (C == MIX_PK1) {
+#define M(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i]));
+#define P(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
+        M(0) P(0) M(1) P(2) M(2) P(4) M(3) P(6)
+      } else if (C == MIX_PK3) {
+        M(0) M(1) M(2) P(0) M(4) M(5) M(6) P(4)
+      } else if (C == MIX_PK_2OF3) {
+        M(0) P(0) P(2) M(1) P(4) P(6) M(2) P(1)
+#undef P
+      } else if (C == PKADD) {
+#define P(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
+        P(0) P(1) P(2) P(3) P(4) P(5) P(6) P(7)
+      } else if (C == MIX_PKADD1) {
+#define A(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i]));
+        A(0) P(0) A(1) P(2) A(2) P(4) A(3) P(6)
+#undef A
+#undef P
+#undef M
       } else if (C == TRANS_MIX) {
 #define S(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i]));
         S(0) S(1) S(2) S(3) S(4) S(5) S(6)
@@ -286,10 +306,12 @@ template <int C> void run(int waves_per_simd, int n_cu) {
 
 template <int C> void all(int n_cu) { for (int w : {1, 2, 4}) run<C>(w, n_cu); }
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   const int n = p.multiProcessorCount;
   printf("device %s, %d CUs\n", p.name, n);
+  all<MIX_PK1>(n); all<MIX_PK3>(n); all<MIX_PK_2OF3>(n); all<PKADD>(n); all<MIX_PKADD1>(n);
+  if (argc > 1) return 0;                  // any argument: only the packed-arithmetic mixes
   all<ADD>(n); all<MUL>(n); all<ADDMUL>(n); all<FMA3>(n); all<FMA_S>(n); all<MUL_S>(n); all<MIN>(n); all<MAX3>(n); all<MOV>(n); all<CNDMASK>(n);
   all<CMP_VCC>(n); all<CMP_SGPR>(n); all<CMP_CND>(n); all<RCP>(n); all<RSQ>(n); all<SQRT>(n); all<MULLO>(n); all<MULHI>(n); all<XOR>(n); all<ADDU>(n);
   all<PKMUL>(n); all<PKFMA>(n); all<FMA_ADD_MIX>(n); all<TRANS_MIX>(n);
