@@ -412,10 +412,13 @@ __device__ __forceinline__ DevXformTail bound_of(const DevXform* __restrict__ xf
 __device__ __forceinline__ lmask may_hit(const Ray& ray, float l1, lmask live, lmask unit, const DevXformTail& b) {
   const f3 oc = b.nor_y - ray.pos;
   const float bb = dot(oc, ray.dir), oc2 = dot(oc, oc);
-  const float d2 = oc2 - bb * bb;
+  // squared distance from c of the nearest point of the HALF-line: that of the line when c lies ahead (bb > 0), |oc|^2
+  // when it lies behind. v_max drops a NaN operand, but a NaN direction never gets here (`unit`), and a NaN origin makes
+  // oc2 a NaN: both comparisons below are then false.
+  const float bp = __builtin_fmaxf(bb, 0.0f);
+  const float d2 = oc2 - bp * bp;
   const float s = kBoundKappa * l1 + b.bound_a;
-  const float th = s * s;
-  const lmask miss = (TRC_FCMP(d2, th, F_OGT) | (TRC_FCMP(bb, 0.0f, F_OLT) & TRC_FCMP(oc2, th, F_OGT))) & TRC_FCMP(oc2, b.bound_far2, F_OLT);
+  const lmask miss = TRC_FCMP(d2, s * s, F_OGT) & TRC_FCMP(oc2, b.bound_far2, F_OLT);
   return live & ~(miss & unit);
 }
 
@@ -565,14 +568,17 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
     const Affine m = X.m;
     f3 on = bn;                                                     // object-space normal
     if ((cand & is_s) != 0ull) { const f3 sn = normalize_dev(p, cand & is_s); if (lane_of(is_s)) on = sn; }   // Ray.inl:116
-    if ((cand & is_c) != 0ull && lane_of(is_c)) {
-      // Ray.inl:132-137: the first face within EPS in the order -x, +x, -y, +y, -z, else +z
-      on = mk3(0.0f, 0.0f, 1.0f);
-      if (p.z < -0.5f + kEps) on = mk3(0.0f, 0.0f, -1.0f);
-      if (p.y >  0.5f - kEps) on = mk3(0.0f, 1.0f, 0.0f);
-      if (p.y < -0.5f + kEps) on = mk3(0.0f, -1.0f, 0.0f);
-      if (p.x >  0.5f - kEps) on = mk3(1.0f, 0.0f, 0.0f);
-      if (p.x < -0.5f + kEps) on = mk3(-1.0f, 0.0f, 0.0f);
+    if ((cand & is_c) != 0ull) {
+      // Ray.inl:132-137: the first face within EPS in the order -x, +x, -y, +y, -z, else +z -- as lane masks, two selects
+      // per component
+      const lmask x0 = TRC_FCMP(p.x, -0.5f + kEps, F_OLT), x1 = TRC_FCMP(p.x, 0.5f - kEps, F_OGT);
+      const lmask y0 = TRC_FCMP(p.y, -0.5f + kEps, F_OLT), y1 = TRC_FCMP(p.y, 0.5f - kEps, F_OGT);
+      const lmask z0 = TRC_FCMP(p.z, -0.5f + kEps, F_OLT);
+      const lmask onx = x0 | x1, ony = ~onx & (y0 | y1);
+      const f3 cn = mk3(lane_of(x0) ? -1.0f : (lane_of(onx) ? 1.0f : 0.0f),
+                        lane_of(ony & y0) ? -1.0f : (lane_of(ony) ? 1.0f : 0.0f),
+                        lane_of(onx | ony) ? 0.0f : (lane_of(z0) ? -1.0f : 1.0f));
+      if (lane_of(is_c)) on = cn;
     }
     const f3 wn = normalize_dev(xform_dir(m, on), cand);            // Ray.inl:62
     const f3 wpos = xform_point(m, p);                              // Ray.inl:61
