@@ -129,4 +129,36 @@ inline ObjectBound object_bound(const DevObject& o) {
   return out;
 }
 
+// MESH: a sphere in OBJECT space that holds every vertex -- for a round mesh much tighter than the AABB (an icosahedron's
+// AABB lets 4.3 units of projected area through, its circumsphere 3.1), so a third of the rays that pass the AABB
+// (Ray.inl:161-167) can skip the triangle loop. Centre = the AABB's middle (as floats), r = the largest vertex distance.
+// intersect.h calls a ray a certain miss when m2 = l2 - s^2 (l = c - o, s = l . d, the kernel's object-space ray) exceeds
+//   r^2 (1 + 2^-8) + 2^-18 l2
+// -- the first term is `hull_r2`. Margins: m2 itself is off by <= 4 u l2 = 2^-22 l2 (|d| = 1 within 2 u after the
+// re-normalisation of Ray.inl:55); Moeller-Trumbore (Ray.inl:189-226) accepts barycentric coordinates that are off by a few
+// u |o - v0| / |e|, i.e. points up to delta ~ 10 u sqrt(l2) outside the triangle: (r + delta)^2 - r^2 <= 2^-9 r^2 + 2^9 delta^2
+// <= 2^-9 r^2 + 2^-33 l2. Checked like the pre-test (TRC_PAIRS_CHECK builds count culled rays that hit a triangle).
+struct MeshHull { f3 centre; float r2; };
+inline MeshHull mesh_hull(const DevObject& o, const DevTri* tris) {
+  MeshHull h;
+  h.centre = mk3(0.5f * (o.bmin.x + o.bmax.x), 0.5f * (o.bmin.y + o.bmax.y), 0.5f * (o.bmin.z + o.bmax.z));
+  double r2 = 0.0;
+  bool ok = std::isfinite(h.centre.x) && std::isfinite(h.centre.y) && std::isfinite(h.centre.z);
+  for (uint32_t t = 0; t < o.tri_count && ok; ++t) {
+    const DevTri& T = tris[o.tri_first + t];
+    const double v[3][3] = { { T.v0.x, T.v0.y, T.v0.z },
+                             { (double)T.v0.x + T.e1.x, (double)T.v0.y + T.e1.y, (double)T.v0.z + T.e1.z },      // e1 = v1 - v0 rounded: <= u |v|, inside the margin
+                             { (double)T.v0.x + T.e2.x, (double)T.v0.y + T.e2.y, (double)T.v0.z + T.e2.z } };
+    for (int k = 0; k < 3; ++k) {
+      const double dx = v[k][0] - h.centre.x, dy = v[k][1] - h.centre.y, dz = v[k][2] - h.centre.z;
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      if (!std::isfinite(d2)) ok = false;
+      r2 = std::fmax(r2, d2);
+    }
+  }
+  const double padded = r2 * (1.0 + 1.0 / 256.0);
+  h.r2 = (ok && padded < 1e37) ? std::nextafter((float)padded, std::numeric_limits<float>::infinity()) : std::numeric_limits<float>::infinity();
+  return h;
+}
+
 }  // namespace trc

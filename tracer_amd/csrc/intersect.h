@@ -241,7 +241,6 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
   float best = FLT_MAX;
   bn = splat3(0.0f);
   if (__builtin_expect(mask == 0ull || count == 0u, 0)) return best;
-  if (TRC_SECTION == 0 && TRC_PAIRS_CHECK == 0 && lane_of(mask)) tri_tests += count;
   const unsigned lane = lane_id();
   const unsigned G = count < 64u ? count : 64u;                  // triangles side by side in one pass
   const unsigned R = ex.rays_per_pass;                           // 64 / G rays side by side
@@ -490,12 +489,16 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
   const lmask is_c = valid & ~(is_s | is_m);
   float th = -1.0f;                                                 // the pair's object-space t
   lmask cand = 0ull;                                                // pairs with a hit at t > 0 (Ray.inl:72)
-  if (is_s != 0ull) {
-    // Ray.inl:103-118: radius 0.5, geometric method
-    const f3 l = -r.pos;
+  lmask hull_miss = 0ull;                                           // mesh pairs whose ray passes outside the sphere that holds the vertices
+  if ((is_s | is_m) != 0ull) {
+    // Ray.inl:103-118: radius 0.5 about the origin, geometric method -- and, in the same instructions, a mesh pair's
+    // ray against the sphere that holds the mesh's vertices (centre hull_c: bound.h, mesh_hull)
+    f3 l = -r.pos;
+    if (lane_of(is_m)) l = mk3(X.hull_cx, X.hull_cy, X.hull_cz) - r.pos;
     const float s = dot(l, r.dir);
     const float l2 = dot(l, l);
     const float m2 = l2 - s * s;
+    hull_miss = is_m & TRC_FCMP(m2, __builtin_fmaf(0x1p-18f, l2, X.hull_r2), F_OGT);
     const lmask outside = TRC_FCMP(l2, 0.25f, F_OGT);
     const lmask hit = is_s & ~(TRC_FCMP(s, 0.0f, F_OLT) & outside) & ~TRC_FCMP(m2, 0.25f, F_OGT);
     const float q = cr_sqrt(0.25f - m2, hit);
@@ -520,14 +523,18 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
       float tb = FLT_MAX;
       const uint32_t ray_slot = sc.mesh_keys != nullptr ? (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)slot) : 0u;
       for (uint32_t j = 0; j < sc.n_mesh; ++j) {
-        const lmask mj = pass_m & TRC_UCMP(k, mesh_first + j, I_EQ);
-        if (mj == 0ull) continue;
+        const lmask aj = pass_m & TRC_UCMP(k, mesh_first + j, I_EQ);
+        if (aj == 0ull) continue;
         const DevMeshExtra ex = load_uniform(&sc.meshes[j]);
+        // a ray that passes the AABB counts the mesh's triangle tests (Ray.inl:168-170 runs them all); the tests themselves
+        // are only for the rays that can reach a vertex (checking builds test every ray)
+        if (TRC_SECTION == 0 && TRC_PAIRS_CHECK == 0 && lane_of(aj)) tri_tests += ex.tri_count;
+        const lmask mj = TRC_PAIRS_CHECK ? aj : aj & ~hull_miss;
+        if (mj == 0ull) continue;
         if (sc.mesh_keys != nullptr && ex.big_slot != kNotBig) {
           // a big mesh whose brute-force pass ran before this kernel (kernels.hip: k_mesh_brute): the winning face
           // is evaluated once more for its normal (same arithmetic, same t)
           if (lane_of(mj)) {
-            if (TRC_SECTION == 0 && TRC_PAIRS_CHECK == 0) tri_tests += ex.tri_count;
             const unsigned long long key = sc.mesh_keys[(size_t)ex.big_slot * sc.key_stride + ray_slot];
             if ((uint32_t)(key >> 32) != 0x7f7fffffu) {
               f3 n;
@@ -549,6 +556,7 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
       TRC_SECT_END(4, tri_tests);
     }
   }
+  if (TRC_PAIRS_CHECK == 1 && lane_of(hull_miss & cand)) ++tri_tests;           // a culled mesh pair that hit a triangle after all
   if (TRC_PAIRS_CHECK == 1 && f.flagged && lane_of(cand | (valid & is_m & box_pass))) {
     ++tri_tests;
 #ifdef TRC_PAIRS_CHECK_PRINT

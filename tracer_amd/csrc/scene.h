@@ -73,15 +73,16 @@ struct alignas(16) DevXform {      // 160 bytes
   f3       nor_y;                  // PLANE: world normal of object-space +y, what a hit reports; SPHERE / CUBE / MESH: centre of the
                                    // object's world-space bounding sphere (bound.h)
   uint32_t id;                     // index in the caller's Object[] (Hit::m_id)
-  uint32_t mi_pat;                 // XformPattern of mi this object is filed under (sparse_xform.h)
+  float    hull_r2;                // MESH: squared radius (with its margin, bound.h: mesh_hull) of the sphere about hull_c that holds
+                                   // every vertex of the mesh, in OBJECT space -- tighter than the AABB for round meshes
   float    bound_a, bound_far2;    // SPHERE / CUBE / MESH: bound.h (radius + the constant part of the slack; far limit)
-  uint32_t pad;
-  f3       bmin; uint32_t pad1;    // MESH: Mesh::m_bmin / m_bmax once more (DevMeshExtra), where a per-lane gather of the record finds them
-  f3       bmax; uint32_t pad2;
+  float    hull_cx;
+  f3       bmin; float hull_cy;    // MESH: Mesh::m_bmin / m_bmax once more (DevMeshExtra), where a per-lane gather of the record finds them
+  f3       bmax; float hull_cz;
 };
 static_assert(sizeof(DevXform) == 160, "DevXform");
 // the 32 bytes behind the matrices, as one record (what the (ray, object) pre-test reads)
-struct alignas(16) DevXformTail { f3 nor_y; uint32_t id; uint32_t mi_pat; float bound_a, bound_far2; uint32_t pad; };
+struct alignas(16) DevXformTail { f3 nor_y; uint32_t id; float hull_r2; float bound_a, bound_far2; float hull_cx; };
 static_assert(sizeof(DevXformTail) == 32 && offsetof(DevXform, nor_y) == 96 && offsetof(DevXform, bound_far2) == 96 + 24, "DevXformTail");
 struct alignas(16) DevCubeExtra { f3 axis_nor[6]; float pad[2]; };                 // 80 bytes
 struct alignas(16) DevMeshExtra {

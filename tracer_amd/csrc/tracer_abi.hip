@@ -318,11 +318,14 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
       if (o.mesh_type != order[g] || filed_pattern(o) != pat) continue;
       DevXform x; memset(&x, 0, sizeof x);
       x.mi = o.mi; x.m = o.m; x.nor_y = o.axis_nor[3]; x.id = (uint32_t)i;
-      x.mi_pat = pat;
       if (o.mesh_type != REF_PLANE) {                 // the (ray, object) pre-test of intersect.h
         const ObjectBound b = object_bound(o);
         x.nor_y = b.centre; x.bound_a = b.a; x.bound_far2 = b.far2;
         x.bmin = o.bmin; x.bmax = o.bmax;
+        if (o.mesh_type == REF_MESH) {
+          const MeshHull hull = mesh_hull(o, tris.data());
+          x.hull_r2 = hull.r2; x.hull_cx = hull.centre.x; x.hull_cy = hull.centre.y; x.hull_cz = hull.centre.z;
+        }
       }
       xf.push_back(x);
       if (o.mesh_type == REF_CUBE) {
