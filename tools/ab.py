@@ -15,8 +15,13 @@ CHILD = r'''
 import os, sys, json
 sys.path.insert(0, %r)
 import tracer_amd as ta
-pipe, reps, variant, w, h, iters = [int(x) for x in sys.argv[1:7]]
-sc = ta.Scene(variant); cam = ta.camera_default(w, h)
+pipe, reps, variant, w, h, iters, clutter = [int(x) for x in sys.argv[1:8]]
+if clutter:
+    sys.path.insert(0, os.path.join(%r, "tests"))
+    from scene_gen import clutter_scene
+    sc = ta.Scene(path=clutter_scene("/tmp/ab_clutter_%%d.scene" %% clutter, clutter), aspect=(w, h)); cam = sc.camera
+else:
+    sc = ta.Scene(variant); cam = ta.camera_default(w, h)
 tr = ta.Tracer(w, h); tr.set_pipeline(pipe); tr.upload_scene(sc.objects_ptr, sc.size)
 ms = []
 for r in range(reps + 3):
@@ -24,7 +29,7 @@ for r in range(reps + 3):
     if r >= 3: ms.append(tr.last_kernel_ms())
 tr.reset_counters(); tr.pathtrace(cam, 1, 1, iters); c = tr.counters()
 print(json.dumps({"ms": ms, "segs": c["live_segments"], "mhz": c["shader_mhz"]}))
-''' % HERE
+''' % (HERE, HERE)
 
 
 def main():
@@ -35,6 +40,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--size", type=int, nargs=2, default=[512, 512])
     ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--clutter", type=int, default=0, help="seed of a random 29-object scene (tests/scene_gen.py) instead of the Cornell box")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     libs = [x.split("=", 1) for x in a.libs]
@@ -47,7 +53,7 @@ def main():
                 env["TRC_LIB"] = os.path.abspath(path)
             else:
                 env.pop("TRC_LIB", None)
-            out = subprocess.run([sys.executable, "-c", CHILD, str(a.pipe), str(a.reps), str(a.variant), str(a.size[0]), str(a.size[1]), str(a.iters)],
+            out = subprocess.run([sys.executable, "-c", CHILD, str(a.pipe), str(a.reps), str(a.variant), str(a.size[0]), str(a.size[1]), str(a.iters), str(a.clutter)],
                                  env=env, capture_output=True, text=True, timeout=600)
             if out.returncode != 0:
                 print(name, "FAILED", out.stderr[-2000:]); sys.exit(1)
