@@ -548,24 +548,36 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
 #ifndef TRC_BOUNCE_WAVES
 #define TRC_BOUNCE_WAVES 5         // resident waves per SIMD k_bounce is compiled for (6 = 80 VGPRs spills since the (ray, object) pairs)
 #endif
+// A workgroup walks its region's queue in steps of `bpr` workgroups (bpr = the workgroups per region of THIS launch,
+// capped by the launcher), so that the set-up -- the LDS copy of the DevXform table, the kernel arguments, the counters --
+// is paid once per workgroup and not once per 256 paths. Measured on the headline workload (512 workgroups per region
+// when every one takes 256 paths = 11.53 ms): cap 5 / 10 / 20 -> 12.5 / 12.6 / 11.7 ms (a wavefront's trips are serial:
+// load the state, trace, store -- too few of them in flight to hide the HBM latency), 40 / 80 -> 11.31, 160 -> 11.72.
+#ifndef TRC_BOUNCE_BPR
+#define TRC_BOUNCE_BPR 64
+#endif
 template <bool COMPACT, bool LDS_GATHER, bool FIRST>
 __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
-                                                  uint32_t n_slots, int depth,
+                                                  uint32_t n_slots, int depth, uint32_t bpr,
                                                   PathState cur, PathState next,
                                                   const uint32_t* __restrict__ count_in,
                                                   uint32_t* __restrict__ count_out,
                                                   float* __restrict__ stage, DeviceCounters* counters) {
   const uint32_t cap = region_cap(n_slots);
-  const RegionView rv = region_view(n_slots, cap, (COMPACT && !FIRST) ? count_in : nullptr);
-  if (rv.first >= rv.n_in) return;                                    // whole block past its region's queue
+  const uint32_t p = blockIdx.x / bpr;                                // this workgroup's region
+  const uint32_t n_in = (COMPACT && !FIRST) ? count_in[p * kCountStride] : region_initial(n_slots, cap, p);
+  uint32_t first = (blockIdx.x - p * bpr) * kBlock;
+  if (first >= n_in) return;                                          // whole block past its region's queue
   __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];              // as in k_queue: table of the held candidates' gathers
   if (LDS_GATHER) {
     const uint32_t n_dw = gather_records(fp.sc) * (uint32_t)(sizeof(DevXform) / 4);
     for (uint32_t k = threadIdx.x; k < n_dw; k += kBlock) ((uint32_t*)s_xf)[k] = ((const uint32_t*)fp.sc.xf)[k];
     __syncthreads();
   }
-  const uint32_t i = rv.p * cap + rv.first + threadIdx.x;
-  const bool in_queue = rv.first + threadIdx.x < rv.n_in;
+  uint32_t tt = 0, n_live = 0, n_paths = 0;
+  for (; first < n_in; first += bpr * kBlock) {
+  const uint32_t i = p * cap + first + threadIdx.x;
+  const bool in_queue = first + threadIdx.x < n_in;
   const int32_t task = !in_queue ? -1 : FIRST ? (int32_t)i : cur.pixel[i];     // initially slot == task (raytrace.cu:101)
   const bool active = task >= 0;                                      // raytrace.cu:119-124
   uint32_t s = 0;
@@ -573,11 +585,10 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(FrameParams
   const uint32_t pixel = fp.pix0 + s, iter = iter_first + itk * iter_stride;
   Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
   f3 col = splat3(0.0f);
-  uint32_t tt = 0;
   if (FIRST) {
     ray = camera_sample(fp, pixel, iter);                             // initBuffersKernel, raytrace.cu:72-96
     col = splat3(1.0f);                                               // raytrace.cu:99
-    count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, active ? 1ull : 0ull);
+    n_paths += active ? 1u : 0u;
   } else if (active) {
     ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]);
     ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
@@ -597,11 +608,11 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(FrameParams
     const unsigned lane = lane_id();
     const unsigned total = __popcll(mask);
     unsigned base = 0;
-    if (lane == 0 && total) base = atomicAdd(count_out + rv.p * kCountStride, total);
+    if (lane == 0 && total) base = atomicAdd(count_out + p * kCountStride, total);
     base = __builtin_amdgcn_readfirstlane(base);
     if (cont) {
       const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
-      const uint32_t j = rv.p * cap + base + rank;
+      const uint32_t j = p * cap + base + rank;
       next.px[j] = ray.pos.x; next.py[j] = ray.pos.y; next.pz[j] = ray.pos.z;
       next.dx[j] = ray.dir.x; next.dy[j] = ray.dir.y; next.dz[j] = ray.dir.z;
       next.cr[j] = col.x; next.cg[j] = col.y; next.cb[j] = col.z;
@@ -617,7 +628,10 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(FrameParams
       cur.pixel[i] = -1;                                              // raytrace.cu:132,139
     }
   }
-  count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, active ? 1ull : 0ull);
+  n_live += active ? 1u : 0u;
+  }
+  if (FIRST) count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, (unsigned long long)n_paths);
+  count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, (unsigned long long)n_live);
   count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
 }
 
@@ -949,13 +963,17 @@ void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t
   if (fold_raygen) (void)hipMemsetAsync(queue_count, 0, sizeof(uint32_t) * (kPathDepth + 1) * kRegions * kCountStride, stream);
   else hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, cur, queue_count, counters);
   const bool lds = gather_records(fp.sc) <= kGatherMax;
+  // k_bounce: at most TRC_BOUNCE_BPR workgroups per region, each walking the region's queue in that stride
+  const uint32_t bpr_full = region_cap(n_slots) / kBlock;
+  const uint32_t bpr = bpr_full < (uint32_t)TRC_BOUNCE_BPR ? bpr_full : (uint32_t)TRC_BOUNCE_BPR;
+  const dim3 bgrid(kRegions * bpr);
   for (int d = 0; d < kPathDepth; ++d) {
     if (bmp) launch_big_mesh_passes<1>(fp, n_slots, cur, compact ? queue_count + d * kRegions * kCountStride : nullptr, *bmp, stream);
     const bool first = fold_raygen && d == 0;
     const uint32_t* cin = compact ? queue_count + d * kRegions * kCountStride : nullptr;
     uint32_t* cout = compact ? queue_count + (d + 1) * kRegions * kCountStride : nullptr;
     const PathState out = compact ? next : cur;
-#define TRC_LAUNCH_BOUNCE(C, L, F) hipLaunchKernelGGL((k_bounce<C, L, F>), grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, cur, out, cin, cout, stage, counters)
+#define TRC_LAUNCH_BOUNCE(C, L, F) hipLaunchKernelGGL((k_bounce<C, L, F>), bgrid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, bpr, cur, out, cin, cout, stage, counters)
     if (compact) { if (lds) { if (first) TRC_LAUNCH_BOUNCE(true, true, true); else TRC_LAUNCH_BOUNCE(true, true, false); }
                    else     { if (first) TRC_LAUNCH_BOUNCE(true, false, true); else TRC_LAUNCH_BOUNCE(true, false, false); } }
     else         { if (lds) { if (first) TRC_LAUNCH_BOUNCE(false, true, true); else TRC_LAUNCH_BOUNCE(false, true, false); }
