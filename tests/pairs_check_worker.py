@@ -39,6 +39,14 @@ def ray_batches(tr, rng, n=16384):
     out.append(tr.intersect_rays(far))
     ax = a.copy(); ax[:, 3:] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n)] * rng.choice([-1.0, 1.0], (n, 1)).astype(np.float32)
     out.append(tr.intersect_rays(ax))
+    # degenerate rays: NaN / inf coordinates, zero and denormal directions (the pre-test's comparisons are all false for a NaN,
+    # and a direction that is not of unit length keeps every pair)
+    bad = a[:1024].copy()
+    sel = rng.integers(0, 6, len(bad))
+    vals = np.array([np.nan, np.inf, -np.inf, 0.0, 1e-42, 3e38], np.float32)[rng.integers(0, 6, len(bad))]
+    bad[np.arange(len(bad)), sel] = vals
+    bad[::7, 3:] = 0.0
+    out.append(tr.intersect_rays(bad))
     hit = first["ids"] >= 0
     s = a[hit].copy()
     nd = rng.normal(size=(len(s), 3)); nd /= np.linalg.norm(nd, axis=1, keepdims=True)
