@@ -153,3 +153,29 @@ def test_device_resident_batch_and_edge_cases(ta, oracle_c):
     assert L.trc_pick(tr.ctx, C.byref(ta.camera_default(32, 32)), 32, 32, 16, 16, C.byref(i), None, None, None) == 0
     assert i.value == oracle_c.pick(oracle_c.scene_create(0), oracle_c.camera_default(32, 32), 32, 32, 16, 16)[2]
     tr.close()
+
+
+def test_degenerate_rays_vs_oracle(ta, oracle_c):
+    """Rays with a NaN, an infinity, a zero, a denormal or a huge coordinate, and zero directions: what Ray::intersectScene
+    makes of them (mostly "no hit", sometimes a hit with a NaN in it) is reproduced -- ids exactly, floats up to the
+    payload of a NaN. The (ray, object) pre-test must keep every pair of such a ray (its comparisons are false for a NaN,
+    and a direction that is not of unit length switches it off)."""
+    rs = np.random.RandomState(11)
+    n = 1536
+    org = rs.uniform(-4.8, 4.8, (n, 3)).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    vals = np.array([np.nan, np.inf, -np.inf, 0.0, 1e-42, 3e38, -0.0], np.float32)
+    rays[np.arange(n), rs.randint(0, 6, n)] = vals[rs.randint(0, len(vals), n)]
+    rays[::7, 3:] = 0.0
+    for variant in (0, 2):
+        tr = make_tracer(ta, variant, 2)
+        r = tr.intersect_rays(rays)
+        s = oracle_c.scene_create(variant, 2)
+        for i in range(n):
+            t, hid, pos, nor = oracle_c.intersect_scene(s, rays[i])
+            assert hid == r["ids"][i], (variant, i, rays[i])
+            assert np.array_equal(np.float32(t), r["ts"][i], equal_nan=True), (variant, i)
+            assert np.array_equal(pos, r["pos"][i], equal_nan=True) and np.array_equal(nor, r["nor"][i], equal_nan=True), (variant, i)
+        tr.close()

@@ -506,7 +506,7 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
     cand = hit & TRC_FCMP(th, 0.0f, F_OGT);
   }
   f3 bn = splat3(0.0f);                                             // MESH: the winning triangle's un-normalised normal
-  lmask box_pass = 0ull;
+  lmask box_pass = 0ull, tri_hit = 0ull;                            // (tri_hit: mesh pairs whose ray hit a triangle)
   if ((is_c | is_m) != 0ull) {
     // Ray.inl:121-127 (CUBE, bounds +-0.5) and :161-167 (MESH, the mesh's AABB): one slab test
     f3 bmin = splat3(-0.5f), bmax = splat3(0.5f);
@@ -548,15 +548,20 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
           if (lane_of(mj)) { tb = t; bn = n; }
         }
       }
-      // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero normal forward; the
-      // world-space distance test then rejects it (|o + d * FLT_MAX|^2 overflows to inf) -> explicit miss here.
-      // tb > 0 for every hit (mesh_closest / the key pass keep positive t only).
+      // Ray.inl:171-185: with no triangle hit the reference carries t = FLT_MAX and a zero normal forward, i.e. the point
+      // o + d * FLT_MAX; the world-space distance test rejects it because that point's squared distance overflows to inf
+      // (or is a NaN) -- for every d of unit length. The one exception is kept: a direction that overflowed in the
+      // re-normalisation of Ray.inl:55 is the ZERO vector (|M d|^2 = inf, 1 / sqrt(inf) = 0: a caller's ray with
+      // |d| > 1e19), the point is then the origin itself, its distance 0, and the reference reports the mesh "hit" at
+      // t = FLT_MAX with a NaN normal (normalize of the zero vector, below). tb > 0 for every triangle hit.
+      const lmask zero_dir = TRC_FCMP(__builtin_fabsf(r.dir.x) + __builtin_fabsf(r.dir.y) + __builtin_fabsf(r.dir.z), 0.0f, F_OEQ);
       if (lane_of(is_m)) th = tb;
-      cand |= pass_m & TRC_FCMP(tb, FLT_MAX, F_UNE);
+      tri_hit = pass_m & TRC_FCMP(tb, FLT_MAX, F_UNE);
+      cand |= tri_hit | (pass_m & zero_dir);
       TRC_SECT_END(4, tri_tests);
     }
   }
-  if (TRC_PAIRS_CHECK == 1 && lane_of(hull_miss & cand)) ++tri_tests;           // a culled mesh pair that hit a triangle after all
+  if (TRC_PAIRS_CHECK == 1 && lane_of(hull_miss & tri_hit)) ++tri_tests;           // a culled mesh pair that hit a triangle after all
   if (TRC_PAIRS_CHECK == 1 && f.flagged && lane_of(cand | (valid & is_m & box_pass))) {
     ++tri_tests;
 #ifdef TRC_PAIRS_CHECK_PRINT
