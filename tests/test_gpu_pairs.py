@@ -91,6 +91,37 @@ object box
     "single_sphere": "camera fov 30 zoom -13 focal 13 lens 0\n" + WALLS + "mesh ball sphere\nobject ball\n  scale 3 3 3\n  material trans\n  ior 1.5\n",
     "single_cube": "camera fov 30 zoom -13 focal 13 lens 0\n" + WALLS + "mesh box cube\nobject box\n  scale 2 3 2\n  rotate 40 0 1 0\n  translate 1 -2 0\n",
     "single_mesh": "camera fov 30 zoom -13 focal 13 lens 0\n" + WALLS + "mesh ico obj %(data)s/icosahedron.obj\nobject ico\n  scale 2.5\n  rotate 20 1 0 0\n  material mirr\n",
+    # transforms that are singular, tiny or huge: inverses with inf / NaN entries (no bound: every ray keeps its pair), products
+    # that overflow or underflow in the object-space re-normalisation
+    "degenerate_transforms": "camera fov 30 zoom -13 focal 13 lens 0.2\n" + WALLS + """mesh ball sphere
+mesh box cube
+mesh ico obj %(data)s/icosahedron.obj
+object ball
+  scale 2 0 2
+  translate -2 0 0
+object ball
+  scale 1e-20 1e-20 1e-20
+  translate 1 1 0
+object ball
+  scale 1e20 1e20 1e20
+  material trans
+  ior 1.5
+object box
+  scale 3 0 1
+  rotate 30 0 1 1
+  translate 2 -1 0
+object ico
+  scale 1e-19
+  translate 0 -2 1
+object ico
+  scale 2 0 2
+  rotate 45 1 0 0
+  translate -1 2 -1
+  material mirr
+object box
+  scale 1e19 1 1
+  translate 0 3 0
+""",
     # eight meshes side by side (several meshes per pass) and nothing else but the floor and the light
     "many_meshes": "camera fov 30 zoom -13 focal 13 lens 0.2\n" + WALLS + "mesh ico obj %(data)s/icosahedron.obj\nmesh ball2 icosphere ico 1\n" + "".join(
         "object %s\n  scale %g\n  rotate %d 0.2 1 0.3\n  translate %g %g %g\n  material %s\n" % (("ico", "ball2")[k % 2], 0.8 + 0.2 * k, 25 * k,
