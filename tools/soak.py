@@ -1,6 +1,8 @@
 """Parity soak (development aid, run on the GPU box): many seeded random scenes -- cluttered ones and
 axis-aligned ones -- path-traced by every pipeline and compared bit for bit with the CPU oracle.
-    python3 tools/soak.py [first_seed=100] [n_seeds=20]"""
+    python3 tools/soak.py [first_seed=100] [n_seeds=20]
+With TRC_LIB=tracer_amd/variants/libtracer_pairs_check1.so (the checking build of the (ray, object) pre-test, intersect.h) the
+tri_tests counter counts pairs that the pre-test called a certain miss and that hit after all: it must stay zero."""
 import os
 import sys
 import tempfile
@@ -19,6 +21,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 o = Oracle("c")
 o.set_math_mode(Oracle.MATH_PORTABLE)
 bad = 0
+checking = "pairs_check1" in os.environ.get("TRC_LIB", "")
 with tempfile.TemporaryDirectory() as tmp:
     for seed in range(first, first + n):
         r = np.random.default_rng(seed)
@@ -40,6 +43,9 @@ with tempfile.TemporaryDirectory() as tmp:
             tr.set_pipeline(pipe); tr.set_rng_mode(rng); tr.reset_counters()
             tr.pathtrace(sc.camera, seed, 1, iters)
             same = tr.read_film().tobytes() == ref["film"].tobytes() and tr.counters()["live_segments"] == ref["stats"]["live_segments"]
+            if checking and tr.counters()["tri_tests"] != 0:
+                same = False
+                print(f"PRE-TEST VIOLATIONS: {tr.counters()['tri_tests']}", flush=True)
             if not same:
                 bad += 1
                 print(f"MISMATCH seed {seed} pipe {pipe} {w}x{h} iters {iters} rng {rng} objects {sc.size}", flush=True)
