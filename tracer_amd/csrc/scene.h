@@ -61,11 +61,11 @@ static_assert(sizeof(DevObject) == 240, "DevObject");
 
 // ---- device-side layout -------------------------------------------------------------------
 // Objects are GROUPED BY PRIMITIVE TYPE on the device: [planes | spheres | cubes | meshes].
-// Every lane of a wavefront walks the same object list (Ray.inl:70), so a record is read with
-// wave-uniform scalar loads into SGPRs; grouping lets the kernel run type-specialised,
-// branch-free loops that test two objects of one type per trip (two independent dependency
-// chains for the VALU to interleave), and sorting a group by the zero pattern of the matrices lets the
-// loop body leave out the multiplications by exact zeros (sparse_xform.h). The reference's tie rule "lowest object index wins"
+// Every lane of a wavefront walks the same plane list (Ray.inl:70), so a plane's record is read wave-uniformly (scalar
+// loads, or broadcast reads of the kernel's LDS copy); the planes are tested two per trip (two independent dependency
+// chains for the VALU to interleave), and sorting them by the zero pattern of the matrices lets the loop body leave out
+// the multiplications by exact zeros (sparse_xform.h). The other types follow as [spheres | cubes | meshes]: the table
+// that the (ray, object) pairs of intersect.h index per lane. The reference's tie rule "lowest object index wins"
 // (strict `<` in index order, Ray.inl:75) is kept by comparing (distance, original index).
 struct alignas(16) DevXform {      // 160 bytes
   Affine   mi;                     // world -> object (Object::m_matrixi)
@@ -84,7 +84,6 @@ static_assert(sizeof(DevXform) == 160, "DevXform");
 // the 32 bytes behind the matrices, as one record (what the (ray, object) pre-test reads)
 struct alignas(16) DevXformTail { f3 nor_y; uint32_t id; float hull_r2; float bound_a, bound_far2; float hull_cx; };
 static_assert(sizeof(DevXformTail) == 32 && offsetof(DevXform, nor_y) == 96 && offsetof(DevXform, bound_far2) == 96 + 24, "DevXformTail");
-struct alignas(16) DevCubeExtra { f3 axis_nor[6]; float pad[2]; };                 // 80 bytes
 struct alignas(16) DevMeshExtra {
   f3 bmin; uint32_t tri_first; f3 bmax; uint32_t tri_count;
   // cooperative test (intersect.h): G = min(tri_count, 64) triangles side by side, 64 / G rays per pass;
@@ -99,14 +98,13 @@ constexpr uint32_t kNotBig = 0xFFFFFFFFu;
 constexpr uint32_t kBigMeshTris = 1024;     // from here on a mesh gets its own brute-force pass
 constexpr uint32_t kMeshTile = 256;         // triangles per LDS tile of that pass
 struct alignas(16) DevMaterial  { f3 color; float emit; float brdf; float ior; int32_t mat_type; float inv_ior; };   // inv_ior = 1.0f / ior
-static_assert(sizeof(DevCubeExtra) == 80 && sizeof(DevMeshExtra) == 48 && sizeof(DevMaterial) == 32, "extras");
+static_assert(sizeof(DevMeshExtra) == 48 && sizeof(DevMaterial) == 32, "extras");
 
 struct DevTri;
 struct HotTri;
 // Pointers into ONE device allocation holding the packed scene.
 struct DevScene {
   const DevXform*     xf;          // n_plane + n_sphere + n_cube + n_mesh records, in that order
-  const DevCubeExtra* cubes;       // n_cube
   const DevMeshExtra* meshes;      // n_mesh
   const DevMaterial*  mats;        // nobj, indexed by ORIGINAL object index
   const DevTri*       tris;        // triangle stream
@@ -118,11 +116,10 @@ struct DevScene {
   // persistent pipelines, which test big meshes inside closest_hit() like small ones.
   const unsigned long long* mesh_keys;
   uint32_t key_stride, n_big;
-  // Within a type the records are sorted by the zero pattern of mi (XformPattern order: FULL, DIAG, BLOCK_X,
-  // BLOCK_Y, BLOCK_Z), so that the kernels run one specialised loop per pattern. plane_end[P] = end of pattern
-  // P's run among the planes (BLOCK_Z's ends at n_plane); spheres and cubes distinguish FULL | DIAG only;
-  // meshes are not sorted (always the full product).
-  uint32_t plane_end[4], sphere_full, cube_full;
+  // The planes are sorted by the zero pattern of mi (XformPattern order: FULL, DIAG, BLOCK_X, BLOCK_Y, BLOCK_Z), so that
+  // the kernels run one specialised loop per pattern. plane_end[P] = end of pattern P's run (BLOCK_Z's ends at n_plane).
+  // Spheres, cubes and meshes are tested as (ray, object) pairs with a per-lane matrix: always the full product.
+  uint32_t plane_end[4];
 };
 
 // Triangle stream: faces pre-gathered at upload (replaces the Face -> verts/norms double

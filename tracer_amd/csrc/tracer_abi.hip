@@ -292,20 +292,17 @@ int flatten_scene(const RefObject* objs, uint32_t count, std::vector<DevObject>&
   return TRC_OK;
 }
 
-// The zero pattern of m_matrixi an object is filed under (scene.h: DevScene::plane_end): planes use all five,
-// spheres and cubes FULL | DIAG, meshes FULL.
+// The zero pattern of m_matrixi an object is filed under (scene.h: DevScene::plane_end): planes use all five, the
+// other types are not sorted (caller order within the type).
 uint32_t filed_pattern(const DevObject& o) {
-  const uint32_t pat = classify_xform(o.mi);
-  if (o.mesh_type == REF_PLANE) return pat;
-  if (o.mesh_type == REF_MESH) return XP_FULL;
-  return pat == XP_DIAG ? XP_DIAG : XP_FULL;
+  return o.mesh_type == REF_PLANE ? classify_xform(o.mi) : (uint32_t)XP_FULL;
 }
 
 // Group the flattened objects by primitive type and lay everything out in one buffer
 // (scene.h: DevScene). `base` is the device address the buffer will live at.
 size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>& tris,
                   std::vector<unsigned char>& blob, std::vector<BigMesh>& big) {
-  std::vector<DevXform> xf; std::vector<DevCubeExtra> cubes; std::vector<DevMeshExtra> meshes;
+  std::vector<DevXform> xf; std::vector<DevMeshExtra> meshes;
   std::vector<HotTri> hot;
   std::vector<float> bound;          // 4 floats per `hot` record
   big.clear();
@@ -328,11 +325,7 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
         }
       }
       xf.push_back(x);
-      if (o.mesh_type == REF_CUBE) {
-        DevCubeExtra e; memset(&e, 0, sizeof e);
-        for (int k = 0; k < 6; ++k) e.axis_nor[k] = o.axis_nor[k];
-        cubes.push_back(e);
-      } else if (o.mesh_type == REF_MESH) {
+      if (o.mesh_type == REF_MESH) {
         DevMeshExtra e; e.bmin = o.bmin; e.tri_first = o.tri_first; e.bmax = o.bmax; e.tri_count = o.tri_count;
         const uint32_t G = o.tri_count < 64u ? (o.tri_count ? o.tri_count : 1u) : 64u;
         e.group_magic = 65535u / G + 1u; e.rays_per_pass = 64u / G;
@@ -374,7 +367,6 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
   };
   blob.clear();
   append(xf.data(), xf.size() * sizeof(DevXform));
-  append(cubes.data(), cubes.size() * sizeof(DevCubeExtra));
   append(meshes.data(), meshes.size() * sizeof(DevMeshExtra));
   append(mats.data(), mats.size() * sizeof(DevMaterial));
   append(tris.data(), tris.size() * sizeof(DevTri));
@@ -390,15 +382,14 @@ DevScene scene_pointers(const std::vector<DevObject>& objs, const std::vector<De
   for (const DevObject& o : objs) {
     const uint32_t pat = filed_pattern(o);
     if (o.mesh_type == REF_PLANE) { ++sc.n_plane; ++plane_pat[pat]; }
-    else if (o.mesh_type == REF_SPHERE) { ++sc.n_sphere; sc.sphere_full += pat == XP_FULL; }
-    else if (o.mesh_type == REF_CUBE) { ++sc.n_cube; sc.cube_full += pat == XP_FULL; }
+    else if (o.mesh_type == REF_SPHERE) ++sc.n_sphere;
+    else if (o.mesh_type == REF_CUBE) ++sc.n_cube;
     else ++sc.n_mesh;
   }
   for (uint32_t pat = XP_FULL, end = 0; pat < XP_BLOCK_Z; ++pat) { end += plane_pat[pat]; sc.plane_end[pat] = end; }
   auto up = [](size_t n) { return (n + 255) & ~size_t(255); };
   unsigned char* p = (unsigned char*)base;
   sc.xf = (const DevXform*)p;         p += up(objs.size() * sizeof(DevXform));
-  sc.cubes = (const DevCubeExtra*)p;  p += up(sc.n_cube * sizeof(DevCubeExtra));
   sc.meshes = (const DevMeshExtra*)p; p += up(sc.n_mesh * sizeof(DevMeshExtra));
   sc.mats = (const DevMaterial*)p;    p += up(objs.size() * sizeof(DevMaterial));
   sc.tris = (const DevTri*)p;         p += up(tris.size() * sizeof(DevTri));
