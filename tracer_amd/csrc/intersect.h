@@ -398,7 +398,7 @@ __device__ __forceinline__ float pull(int addr, float v) {      // v of the lane
 }
 
 // The lanes of `live` whose ray MAY hit object k of the [spheres | cubes | meshes] table (bound.h).
-// l1 = |p|_1 of the ray's origin; unit = the lanes whose direction has |d.d - 1| < 2^-16. Every comparison is false
+// l1k = kappa |p|_1 of the ray's origin; unit = the lanes whose direction has |d.d - 1| < 2^-16. Every comparison is false
 // for a NaN, so a ray with a NaN coordinate keeps all its pairs.
 template <int SRC>
 __device__ __forceinline__ DevXformTail bound_of(const DevXform* __restrict__ xf, const DevXform* __restrict__ xl, uint32_t k) {
@@ -408,15 +408,17 @@ __device__ __forceinline__ DevXformTail bound_of(const DevXform* __restrict__ xf
   return (TRC_BOUND_LDS && SRC == XF_LDS) ? *reinterpret_cast<const DevXformTail*>(&xl[k].nor_y)
                                           : load_uniform(reinterpret_cast<const DevXformTail*>(&xf[k].nor_y));
 }
-__device__ __forceinline__ lmask may_hit(const Ray& ray, float l1, lmask live, lmask unit, const DevXformTail& b) {
+__device__ __forceinline__ lmask may_hit(const Ray& ray, float l1k, lmask live, lmask unit, const DevXformTail& b) {
+  // (fused multiply-adds here: this arithmetic is the pre-test's own, not the reference's -- it only has to be accurate)
   const f3 oc = b.nor_y - ray.pos;
-  const float bb = dot(oc, ray.dir), oc2 = dot(oc, oc);
+  const float bb = __builtin_fmaf(oc.z, ray.dir.z, __builtin_fmaf(oc.y, ray.dir.y, oc.x * ray.dir.x));
+  const float oc2 = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, oc.x * oc.x));
   // squared distance from c of the nearest point of the HALF-line: that of the line when c lies ahead (bb > 0), |oc|^2
   // when it lies behind. v_max drops a NaN operand, but a NaN direction never gets here (`unit`), and a NaN origin makes
   // oc2 a NaN: both comparisons below are then false.
   const float bp = __builtin_fmaxf(bb, 0.0f);
-  const float d2 = oc2 - bp * bp;
-  const float s = kBoundKappa * l1 + b.bound_a;
+  const float d2 = __builtin_fmaf(-bp, bp, oc2);
+  const float s = l1k + b.bound_a;                                  // l1k = kappa |p|_1
   const lmask miss = TRC_FCMP(d2, s * s, F_OGT) & TRC_FCMP(oc2, b.bound_far2, F_OLT);
   return live & ~(miss & unit);
 }
@@ -431,8 +433,9 @@ __device__ __forceinline__ void pairs_collect(const Ray& ray, lmask live, uint32
   if (k >= n_obj) return;
   MeshSlot* __restrict__ slots = wave_slots();
   const unsigned lane = lane_id();
-  const float l1 = __builtin_fabsf(ray.pos.x) + __builtin_fabsf(ray.pos.y) + __builtin_fabsf(ray.pos.z);
-  const lmask unit = TRC_FCMP(__builtin_fabsf(dot(ray.dir, ray.dir) - 1.0f), 0x1p-16f, F_OLT);
+  const float l1 = kBoundKappa * (__builtin_fabsf(ray.pos.x) + __builtin_fabsf(ray.pos.y) + __builtin_fabsf(ray.pos.z));
+  const float dd = __builtin_fmaf(ray.dir.z, ray.dir.z, __builtin_fmaf(ray.dir.y, ray.dir.y, ray.dir.x * ray.dir.x));
+  const lmask unit = TRC_FCMP(__builtin_fabsf(dd - 1.0f), 0x1p-16f, F_OLT);
   // two objects per trip: both records are read before the first is tested
   while (k < n_obj) {
     const bool two = k + 1u < n_obj;
