@@ -243,7 +243,8 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
   if (__builtin_expect(mask == 0ull || count == 0u, 0)) return best;
   const unsigned lane = lane_id();
   const unsigned G = count < 64u ? count : 64u;                  // triangles side by side in one pass
-  const unsigned R = ex.rays_per_pass;                           // 64 / G rays side by side
+  const unsigned R = ex.rays_per_pass & 0xffu;                   // 64 / G rays side by side
+  const unsigned R_magic = ex.rays_per_pass >> 8;                // n / R == (n * R_magic) >> 16 for n < 128
   const unsigned n_chunks = (count + 63u) >> 6;
   lmask todo = mask;
   do {
@@ -255,7 +256,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
   const unsigned n_pass = __popcll(round);
   // cost model (VALU instructions per wave): pair enumeration ~ ceil(n_pass / R) * n_chunks * 110,
   // ray-per-lane ~ count * 95
-  if (__builtin_expect(((n_pass + R - 1u) / R) * n_chunks * 5u <= count * 4u, 1)) {
+  if (__builtin_expect((((n_pass + R - 1u) * R_magic) >> 16) * n_chunks * 5u <= count * 4u, 1)) {
     MeshSlot* __restrict__ slots = wave_slots();
     const unsigned rank = __popcll(round & ((1ull << lane) - 1ull));      // < n_pass <= TRC_MESH_SLOTS
     const unsigned long long KEY_NONE = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // t = FLT_MAX
@@ -360,7 +361,10 @@ __device__ __forceinline__ void planes(Closest& c, const Ray& ray, lmask live, c
     const float tp = -r[k].pos.y / r[k].dir.y;
     const f3 p = r[k].pos + tp * r[k].dir;
     // Ray.inl:148-149  x < 0.5 && x > -0.5 is |x| < 0.5 for every float (NaN fails both forms); |.| is a source modifier
-    const lmask in = TRC_FCMP(__builtin_fabsf(p.x), 0.5f, F_OLT) & TRC_FCMP(__builtin_fabsf(p.z), 0.5f, F_OLT);
+    // (one comparison for both. v_max drops a NaN operand; one of p.x, p.z is a NaN without the other only for an infinite tp
+    // times a zero direction component -- the other component is then not zero (dir.y is: tp = -pos.y / dir.y), its
+    // coordinate infinite, and the test fails either way)
+    const lmask in = TRC_FCMP(__builtin_fmaxf(__builtin_fabsf(p.x), __builtin_fabsf(p.z)), 0.5f, F_OLT);
     hold(c, ray, xg, h, live & in & TRC_FCMP(tp, 0.0f, F_OGT), tp, p, first + k);
   }
 }

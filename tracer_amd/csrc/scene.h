@@ -87,7 +87,8 @@ static_assert(sizeof(DevXformTail) == 32 && offsetof(DevXform, nor_y) == 96 && o
 struct alignas(16) DevMeshExtra {
   f3 bmin; uint32_t tri_first; f3 bmax; uint32_t tri_count;
   // cooperative test (intersect.h): G = min(tri_count, 64) triangles side by side, 64 / G rays per pass;
-  // lane / G == (lane * group_magic) >> 16 for lane < 64
+  // lane / G == (lane * group_magic) >> 16 for lane < 64; rays_per_pass = R | (65535 / R + 1) << 8, R = 64 / G:
+  // n / R == (n * (rays_per_pass >> 8)) >> 16 for n < 128
   uint32_t group_magic, rays_per_pass;
   // big meshes (tri_count >= kBigMeshTris): number among the scene's big meshes (row of the per-ray
   // key table of the brute-force pass, kernels.hip: k_mesh_brute) and first record in DevScene::hot;

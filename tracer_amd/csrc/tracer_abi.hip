@@ -328,7 +328,7 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
       if (o.mesh_type == REF_MESH) {
         DevMeshExtra e; e.bmin = o.bmin; e.tri_first = o.tri_first; e.bmax = o.bmax; e.tri_count = o.tri_count;
         const uint32_t G = o.tri_count < 64u ? (o.tri_count ? o.tri_count : 1u) : 64u;
-        e.group_magic = 65535u / G + 1u; e.rays_per_pass = 64u / G;
+        e.group_magic = 65535u / G + 1u; e.rays_per_pass = (64u / G) | ((65535u / (64u / G) + 1u) << 8);
         e.big_slot = kNotBig; e.hot_first = 0;
         if (o.tri_count >= kBigMeshTris) {
           // the 36 bytes per triangle that every test of the brute-force pass reads, padded to whole
