@@ -510,7 +510,7 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
     const lmask hit = is_s & ~(TRC_FCMP(s, 0.0f, F_OLT) & outside) & ~TRC_FCMP(m2, 0.25f, F_OGT);
     const float q = cr_sqrt(0.25f - m2, hit);
     th = lane_of(outside) ? s - q : s + q;
-    cand = hit & TRC_FCMP(th, 0.0f, F_OGT);
+    cand = hit;                                                     // (and th > 0: one comparison for all types, below)
   }
   f3 bn = splat3(0.0f);                                             // MESH: the winning triangle's un-normalised normal
   lmask box_pass = 0ull, tri_hit = 0ull;                            // (tri_hit: mesh pairs whose ray hit a triangle)
@@ -523,7 +523,7 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
     box_pass = pass;
     const float thc = tNear > 0.0f ? tNear : tFar;                  // Ray.inl:129
     if (lane_of(is_c)) th = thc;
-    cand |= pass & is_c & TRC_FCMP(thc, 0.0f, F_OGT);
+    cand |= pass & is_c;
     const lmask pass_m = pass & is_m;
     if (pass_m != 0ull) {
       TRC_SECT_BEGIN(4, tri_tests);
@@ -568,6 +568,7 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
       TRC_SECT_END(4, tri_tests);
     }
   }
+  cand &= TRC_FCMP(th, 0.0f, F_OGT);                                // Ray.inl:72 (a mesh pair's t is positive or FLT_MAX already)
   if (TRC_PAIRS_CHECK == 1 && lane_of(hull_miss & tri_hit)) ++tri_tests;           // a culled mesh pair that hit a triangle after all
   if (TRC_PAIRS_CHECK == 1 && f.flagged && lane_of(cand | (valid & is_m & box_pass))) {
     ++tri_tests;

@@ -99,12 +99,13 @@ TRC_HD float pm_asin_poly(float x) { // |x| <= 0.5
 // the defining formula, the same product and sum -- so one square root and one polynomial serve all three
 // cases (lanes of a wavefront fall into all of them); pm_sqrtf is sqrtf, correctly rounded either way.
 TRC_HD float pm_acosf(float x) {
-  const float ax = x < 0.0f ? -x : x;
-  const bool tail = ax > 0.5f;
+  // |x| and the sign instead of three comparisons of x (x < 0 ? -x : x differs from |x| only for -0, whose fmaf below
+  // is 0.5 either way; v_cmp is the expensive instruction of the VALU's simple classes)
+  const float ax = __builtin_fabsf(x);
+  const bool tail = ax > 0.5f, neg = x < 0.0f;
   const float s = pm_sqrtf(fmaf(-0.5f, ax, 0.5f));
   const float p = pm_asin_poly(tail ? s : x);
-  if (x > 0.5f) return 2.0f * p;
-  if (x < -0.5f) return fmaf(-2.0f, p, 3.14159274101257324f);
+  if (tail) return neg ? fmaf(-2.0f, p, 3.14159274101257324f) : 2.0f * p;      // x < -1/2 : x > 1/2
   return 1.57079637050628662f - p;
 }
 
