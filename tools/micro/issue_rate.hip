@@ -13,7 +13,7 @@
 #define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 
 enum { ADD, MUL, ADDMUL, FMA3, FMA_S, MUL_S, MIN, MAX3, MOV, CNDMASK, CMP_VCC, CMP_SGPR, CMP_CND, RCP, RSQ, SQRT, MULLO, MULHI, XOR, ADDU, PKMUL, PKFMA,
-       FMA_ADD_MIX, TRANS_MIX, MUL_INLINE, MUL_LITERAL, ADD_E64_NEG, MUL_ABS, FMA_INLINE, CND_SGPRMASK, CND_VCC_FED, READLANE, READFIRST, AND, LSHL, CVT_F32_U32, RNDNE, MAD_U32_U24, BFE, MBCNT, MAX, MIN3, CMP_CLASS, CMP_U32, SUBREV, FMAAK, MIX_SGPR, MIX_CMP, MIX_MIN, MIX_MULLO, MIX_CMP_CND, MIX_SGPR2, MIX_PK1, MIX_PK3, PKADD, MIX_PKADD1, MIX_PK_2OF3, NCLASS };
+       FMA_ADD_MIX, TRANS_MIX, MUL_INLINE, MUL_LITERAL, ADD_E64_NEG, MUL_ABS, FMA_INLINE, CND_SGPRMASK, CND_VCC_FED, READLANE, READFIRST, AND, LSHL, CVT_F32_U32, RNDNE, MAD_U32_U24, BFE, MBCNT, MAX, MIN3, CMP_CLASS, CMP_U32, SUBREV, FMAAK, MIX_SGPR, MIX_CMP, MIX_MIN, MIX_MULLO, MIX_CMP_CND, MIX_SGPR2, MIX_PK1, MIX_PK3, PKADD, MIX_PKADD1, MIX_PK_2OF3, MAD_U64, MIX_MAD_U64, MIX_CND_SGPR, MIX_CND_SGPR1, NCLASS };
 static const char* NAMES[] = {"v_add_f32", "v_mul_f32", "v_add_f32 / v_mul_f32 alternating", "v_fma_f32 (3 vgpr)", "v_fma_f32 (sgpr operand)",
   "v_mul_f32 (sgpr operand)", "v_min_f32", "v_max3_f32", "v_mov_b32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 -> vcc", "v_cmp_lt_f32 -> sgpr pair",
   "v_cmp_lt_f32 vcc + v_cndmask (pair = 2 inst)", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_xor_b32", "v_add_u32",
@@ -25,7 +25,8 @@ static const char* NAMES[] = {"v_add_f32", "v_mul_f32", "v_add_f32 / v_mul_f32 a
   "3 v_mul_f32 + 1 v_mul_f32 sgpr (4 inst)", "3 v_mul_f32 + 1 v_cmp -> sgpr (4 inst)", "3 v_mul_f32 + 1 v_min_f32 (4 inst)", "3 v_mul_f32 + 1 v_mul_lo_u32 (4 inst)",
   "2 v_mul_f32 + v_cmp vcc + v_cndmask vcc (4 inst)", "1 v_mul_f32 + 1 v_mul_f32 sgpr (2 inst)",
   "1 v_mul_f32 + 1 v_pk_mul_f32 (2 inst)", "3 v_mul_f32 + 1 v_pk_mul_f32 (4 inst)", "v_pk_add_f32", "1 v_add_f32 + 1 v_pk_add_f32 (2 inst)",
-  "1 v_mul_f32 + 2 v_pk_mul_f32 (3 inst)"};
+  "1 v_mul_f32 + 2 v_pk_mul_f32 (3 inst)", "v_mad_u64_u32", "3 v_mul_f32 + 1 v_mad_u64_u32 (4 inst)",
+  "3 v_mul_f32 + 1 v_cndmask_b32 e64 sgpr mask (4 inst)", "1 v_mul_f32 + 1 v_cndmask_b32 e64 sgpr mask (2 inst)"};
 
 template <int C>
 __global__ __launch_bounds__(256) void k(unsigned long long* span, unsigned long long* ref, float* out, int iters, float a, float b) {
@@ -259,6 +260,22 @@ __global__ __launch_bounds__(256) void k(unsigned long long* span, unsigned long
 #undef A
 #undef P
 #undef M
+      } else if (C == MAD_U64) {
+#define Q(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d[i]) : "v"(x[i]), "v"(y[i]) : "vcc");
+        Q(0) Q(1) Q(2) Q(3) Q(4) Q(5) Q(6) Q(7)
+      } else if (C == MIX_MAD_U64) {
+#define M(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i]));
+        M(0) M(1) M(2) Q(3) M(4) M(5) M(6) Q(7)
+#undef M
+#undef Q
+      } else if (C == MIX_CND_SGPR) {
+#define M(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i]));
+#define K(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[i]) : "v"(y[i]), "s"(s0));
+        M(0) M(1) M(2) K(3) M(4) M(5) M(6) K(7)
+      } else if (C == MIX_CND_SGPR1) {
+        M(0) K(1) M(2) K(3) M(4) K(5) M(6) K(7)
+#undef M
+#undef K
       } else if (C == TRANS_MIX) {
 #define S(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i]));
         S(0) S(1) S(2) S(3) S(4) S(5) S(6)
@@ -310,6 +327,8 @@ int main(int argc, char** argv) {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   const int n = p.multiProcessorCount;
   printf("device %s, %d CUs\n", p.name, n);
+  all<MAD_U64>(n); all<MIX_MAD_U64>(n); all<MIX_CND_SGPR>(n); all<MIX_CND_SGPR1>(n);
+  if (argc > 2) return 0;                  // two arguments: only the 64-bit multiply-add
   all<MIX_PK1>(n); all<MIX_PK3>(n); all<MIX_PK_2OF3>(n); all<PKADD>(n); all<MIX_PKADD1>(n);
   if (argc > 1) return 0;                  // any argument: only the packed-arithmetic mixes
   all<ADD>(n); all<MUL>(n); all<ADDMUL>(n); all<FMA3>(n); all<FMA_S>(n); all<MUL_S>(n); all<MIN>(n); all<MAX3>(n); all<MOV>(n); all<CNDMASK>(n);
