@@ -122,6 +122,24 @@ object box
   scale 1e19 1 1
   translate 0 3 0
 """,
+    # two BIG meshes (1280 faces each: their brute-force pass runs ahead of the closest-hit kernel in the launch-per-bounce
+    # pipelines and in mode 1, the pairs then read its keys with the owning lane's ray slot) next to a small one
+    "two_big_meshes": "camera fov 30 zoom -13 focal 13 lens 0.2\n" + WALLS + """mesh ico obj %(data)s/icosahedron.obj
+mesh ball3 icosphere ico 3
+object ball3
+  scale 1.6
+  rotate 20 0.3 1 0.1
+  translate -2 -1 0
+  material mirr
+object ball3
+  scale 1.2 2 1.2
+  translate 2 0 1
+  material trans
+  ior 1.5
+object ico
+  scale 1.5
+  translate 0 -3 2
+""",
     # eight meshes side by side (several meshes per pass) and nothing else but the floor and the light
     "many_meshes": "camera fov 30 zoom -13 focal 13 lens 0.2\n" + WALLS + "mesh ico obj %(data)s/icosahedron.obj\nmesh ball2 icosphere ico 1\n" + "".join(
         "object %s\n  scale %g\n  rotate %d 0.2 1 0.3\n  translate %g %g %g\n  material %s\n" % (("ico", "ball2")[k % 2], 0.8 + 0.2 * k, 25 * k,
