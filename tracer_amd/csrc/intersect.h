@@ -401,9 +401,7 @@ __device__ __forceinline__ float pull(int addr, float v) {      // v of the lane
   return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
 }
 
-// The lanes of `live` whose ray MAY hit object k of the [spheres | cubes | meshes] table (bound.h).
-// l1k = kappa |p|_1 of the ray's origin; unit = the lanes whose direction has |d.d - 1| < 2^-16. Every comparison is false
-// for a NaN, so a ray with a NaN coordinate keeps all its pairs.
+// Object k's bounding record (scene.h: DevXformTail), wave-uniform.
 template <int SRC>
 __device__ __forceinline__ DevXformTail bound_of(const DevXform* __restrict__ xf, const DevXform* __restrict__ xl, uint32_t k) {
 #ifndef TRC_BOUND_LDS
@@ -412,6 +410,9 @@ __device__ __forceinline__ DevXformTail bound_of(const DevXform* __restrict__ xf
   return (TRC_BOUND_LDS && SRC == XF_LDS) ? *reinterpret_cast<const DevXformTail*>(&xl[k].nor_y)
                                           : load_uniform(reinterpret_cast<const DevXformTail*>(&xf[k].nor_y));
 }
+// The lanes of `live` whose ray MAY hit the object with bounding record b (bound.h).
+// l1k = kappa |p|_1 of the ray's origin; unit = the lanes whose direction has |d.d - 1| < 2^-16. Every comparison is false
+// for a NaN, so a ray with a NaN coordinate keeps all its pairs.
 __device__ __forceinline__ lmask may_hit(const Ray& ray, float l1k, lmask live, lmask unit, const DevXformTail& b) {
   // (fused multiply-adds here: this arithmetic is the pre-test's own, not the reference's -- it only has to be accurate)
   const f3 oc = b.nor_y - ray.pos;
