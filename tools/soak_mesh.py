@@ -1,7 +1,9 @@
 """Soak of the bounding-sphere pre-test of the big-mesh pass (development aid, run on the GPU box): random big
 meshes (subdivided icosahedra, stretched, placed far from their object-space origin), random cameras; mode 1
 through the default loop (pre-test) and through the loop without it must agree in every bit of every pixel.
-    python3 tools/soak_mesh.py [first_seed=0] [n_seeds=100]"""
+    python3 tools/soak_mesh.py [first_seed=0] [n_seeds=100]
+With TRC_LIB=tracer_amd/variants/libtracer_pairs_check1.so (checking build of intersect.h's (ray, object) pre-test and of the
+mesh hull cull: every pair tested, rejections that hit after all counted in tri_tests) that count must stay zero too."""
 import os
 import sys
 import tempfile
@@ -18,6 +20,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = 0
 seen = 0
+checking = "pairs_check1" in os.environ.get("TRC_LIB", "")
 with tempfile.TemporaryDirectory() as tmp:
     for seed in range(first, first + n):
         r = np.random.default_rng(seed)
@@ -31,10 +34,14 @@ with tempfile.TemporaryDirectory() as tmp:
         tr.upload_scene(sc.objects_ptr, sc.size)
         cam = ta.camera_default(w, h, float(r.uniform(-0.5, 0.5)), float(r.uniform(-0.4, 0.4)))
         out = {}
+        tr.reset_counters()
         for accel in (0, 2):
             tr.set_mesh_accel(accel)
             tr.raytrace1(cam)
             out[accel] = tr.read_hits()
+        if checking and tr.counters()["tri_tests"] != 0:
+            bad += 1
+            print(f"PRE-TEST / HULL VIOLATIONS seed {seed}: {tr.counters()['tri_tests']}", flush=True)
         same = all(out[0][k].tobytes() == out[2][k].tobytes() for k in ("ids", "ts", "pos", "nor"))
         npx = int((out[2]["ids"] == 6).sum())
         seen += npx
