@@ -221,3 +221,42 @@ def test_no_cpu_fallback_without_gpu(product_lib):
     import tracer_amd as ta
     with pytest.raises(ta.TracerError):
         ta.Tracer(16, 16)
+
+
+def test_two_hip_runtimes_are_refused_not_crashed():
+    """INTEGRATION.md, One HIP runtime per process: a process that loaded libtracer_amd.so on the system's libamdhip64 and
+    then mapped PyTorch's bundled copy gets an error from trc_create (before any HIP call -- so this runs without a GPU)
+    instead of a crash inside libhsa-runtime64 later; loaded through tracer_amd.load_library() there is one runtime and
+    the check is silent."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.find_spec("torch")
+    torch_hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec else None
+    if not torch_hip or not os.path.exists(torch_hip):
+        pytest.skip("no PyTorch with a bundled libamdhip64.so here")
+    wrong = r'''
+import ctypes, sys
+L = ctypes.CDLL(sys.argv[1])
+L.trc_last_error_string.restype = ctypes.c_char_p
+ctypes.CDLL(sys.argv[2], mode=ctypes.RTLD_GLOBAL)
+ctx = ctypes.c_void_p()
+rc = L.trc_create(0, 64, 64, None, ctypes.byref(ctx))
+print(rc, L.trc_last_error_string().decode())
+'''
+    p = subprocess.run([sys.executable, "-c", wrong, os.path.join(REPO, "tracer_amd", "libtracer_amd.so"), torch_hip],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.startswith("1 ") and "two HIP runtimes" in p.stdout and "libamdhip64" in p.stdout, p.stdout
+    right = r'''
+import ctypes, sys
+sys.path.insert(0, sys.argv[1])
+import tracer_amd
+L = tracer_amd.load_library()
+ctx = ctypes.c_void_p()
+rc = L.trc_create(0, 64, 64, None, ctypes.byref(ctx))
+print(rc, L.trc_last_error_string().decode())
+'''
+    p = subprocess.run([sys.executable, "-c", right, REPO], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "two HIP runtimes" not in p.stdout, p.stdout          # (on a box without a GPU the call fails later, in hipGetDeviceCount)

@@ -6,6 +6,7 @@
 #include "../../include/tracer_abi.h"
 #include "kernels.h"
 
+#include <link.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,41 @@ namespace {
 thread_local std::string g_last_error;
 
 int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+// One HIP runtime per process. PyTorch wheels bundle a libamdhip64.so of their own with the system
+// library's SONAME; a process that has mapped BOTH (this library loaded first, torch imported afterwards) crashes inside
+// libhsa-runtime64 as soon as both copies touch the GPU, and a torch stream or tensor pointer means nothing to the
+// other copy. Where a context is made or a caller's device memory is bound, the mapped objects are therefore listed
+// and two runtimes are an error, not a crash later (TRC_ALLOW_TWO_HIP_RUNTIMES=1 turns the check off).
+int two_hip_runtimes(std::string& which) {
+  const char* allow = getenv("TRC_ALLOW_TWO_HIP_RUNTIMES");
+  if (allow && allow[0] == '1') return 0;
+  std::vector<std::string> found;
+  dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* data) -> int {
+    const char* name = info->dlpi_name ? info->dlpi_name : "";
+    const char* base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (strncmp(base, "libamdhip64.so", 14) == 0) {
+      auto* v = static_cast<std::vector<std::string>*>(data);
+      bool seen = false;
+      for (const std::string& s : *v) seen = seen || s == name;
+      if (!seen) v->push_back(name);
+    }
+    return 0;
+  }, &found);
+  if (found.size() < 2) return 0;
+  which = found[0];
+  for (size_t i = 1; i < found.size(); ++i) which += " and " + found[i];
+  return (int)found.size();
+}
+#define ONE_HIP_RUNTIME(where)                                                                                              \
+  do {                                                                                                                      \
+    std::string which_;                                                                                                     \
+    if (two_hip_runtimes(which_))                                                                                           \
+      return fail(TRC_ERR_INVALID, std::string(where) + ": two HIP runtimes are mapped into this process (" + which_ +     \
+                  "); load libtracer_amd.so after importing torch (tracer_amd.api.load_library() does) -- see INTEGRATION.md, " \
+                  "One HIP runtime per process");                                                                           \
+  } while (0)
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -436,6 +472,7 @@ int trc_create(int device, uint32_t width, uint32_t height, void* stream, trc_ct
   *out = nullptr;
   if (width == 0 || height == 0 || (uint64_t)width * height > 0x7FFFFFFFull)
     return fail(TRC_ERR_INVALID, "trc_create: bad image size");
+  ONE_HIP_RUNTIME("trc_create");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(TRC_ERR_INVALID, "trc_create: no such device");
@@ -813,6 +850,7 @@ int trc_film_device_ptr(trc_ctx* c, void** dev_ptr) {
 int trc_bind_film(trc_ctx* c, void* dev_ptr) {
   if (!c) return fail(TRC_ERR_INVALID, "null context");
   if (dev_ptr && ((uintptr_t)dev_ptr & 15)) return fail(TRC_ERR_INVALID, "trc_bind_film: pointer not 16-byte aligned");
+  if (dev_ptr) ONE_HIP_RUNTIME("trc_bind_film");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->film = dev_ptr ? (float*)dev_ptr : c->film_own;
