@@ -73,11 +73,11 @@ def measured_valu_mix():
 
 
 def kernel_source_digest():
-    """As tools/pmc_summary.py records it: sha256 over tracer_amd/csrc/*.h, *.hip (the sources travel with the library)."""
+    """As tools/pmc_summary.py records it: sha256 over the device code, tracer_amd/csrc/*.h and kernels.hip (the sources travel with the library)."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(HERE, "tracer_amd", "csrc", "*.h")) + glob.glob(os.path.join(HERE, "tracer_amd", "csrc", "*.hip"))):
+    for f in sorted(glob.glob(os.path.join(HERE, "tracer_amd", "csrc", "*.h")) + [os.path.join(HERE, "tracer_amd", "csrc", "kernels.hip")]):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

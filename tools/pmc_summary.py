@@ -45,11 +45,11 @@ d = {"live_segments": segs, "paths": paths,
      "valu_lane_utilisation_pct": 100 * c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64),
      "wave_occupancy_mean_waves_per_simd": c["SQ_WAVE_CYCLES"] * 4 / (cyc * N_SIMD) if "SQ_WAVE_CYCLES" in c else None}
 def kernel_source_digest():
-    """sha256 over the kernel sources (tracer_amd/csrc/*.h, *.hip): bench.py flags a profile taken from other sources."""
+    """sha256 over the device code (tracer_amd/csrc/*.h, kernels.hip): bench.py flags a profile taken from other sources."""
     import glob, hashlib, os
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(here, "tracer_amd", "csrc", "*.h")) + glob.glob(os.path.join(here, "tracer_amd", "csrc", "*.hip"))):
+    for f in sorted(glob.glob(os.path.join(here, "tracer_amd", "csrc", "*.h")) + [os.path.join(here, "tracer_amd", "csrc", "kernels.hip")]):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
