@@ -241,8 +241,8 @@ def extra_configs(ta):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pipeline", type=int, default=3, help="0 wavefront, 1 compacted, 2 fused, 3 work queue (default), 4 auto (= 3 on this scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and config4_strong")
