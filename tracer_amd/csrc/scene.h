@@ -56,8 +56,12 @@ struct alignas(16) DevObject {
   // product + normalisation is replaced by a table filled on the host with the same IEEE ops.
   f3       axis_nor[6];
   float    pad_[2];
+  // MESH: the sphere that holds every vertex (bound.h: mesh_hull) -- a property of the mesh, computed when it is flattened,
+  // not on every matrix update
+  f3       hull_c;
+  float    hull_r2;
 };
-static_assert(sizeof(DevObject) == 240, "DevObject");
+static_assert(sizeof(DevObject) == 256, "DevObject");
 
 // ---- device-side layout -------------------------------------------------------------------
 // Objects are GROUPED BY PRIMITIVE TYPE on the device: [planes | spheres | cubes | meshes].

@@ -322,6 +322,8 @@ int flatten_scene(const RefObject* objs, uint32_t count, std::vector<DevObject>&
         t.n0 = m.norms[fc.n[0]]; t.n1 = m.norms[fc.n[1]]; t.n2 = m.norms[fc.n[2]];
         out_tris.push_back(t);
       }
+      const MeshHull hull = mesh_hull(d, out_tris.data());
+      d.hull_c = hull.centre; d.hull_r2 = hull.r2;
     }
     out_objs[i] = d;
   }
@@ -355,10 +357,7 @@ size_t pack_scene(const std::vector<DevObject>& objs, const std::vector<DevTri>&
         const ObjectBound b = object_bound(o);
         x.nor_y = b.centre; x.bound_a = b.a; x.bound_far2 = b.far2;
         x.bmin = o.bmin; x.bmax = o.bmax;
-        if (o.mesh_type == REF_MESH) {
-          const MeshHull hull = mesh_hull(o, tris.data());
-          x.hull_r2 = hull.r2; x.hull_cx = hull.centre.x; x.hull_cy = hull.centre.y; x.hull_cz = hull.centre.z;
-        }
+        if (o.mesh_type == REF_MESH) { x.hull_r2 = o.hull_r2; x.hull_cx = o.hull_c.x; x.hull_cy = o.hull_c.y; x.hull_cz = o.hull_c.z; }
       }
       xf.push_back(x);
       if (o.mesh_type == REF_MESH) {
