@@ -1,6 +1,8 @@
 """Live comparison of the plain-C oracle with the reference-linked host build
 (oracle/_ref/libtracer_ref.so) on inputs the fixtures do not cover. Skipped where the
 reference build is absent."""
+import os
+
 import numpy as np
 import pytest
 
@@ -125,3 +127,43 @@ def test_portable_math_reference_build(oracle_c, oracle_ref, variant):
         assert np.array_equal(P.tonemap(films, 7.0), oracle_c.tonemap(films, 7.0))
     finally:
         oracle_c.set_math_mode(pyoracle.Oracle.MATH_LIBM)
+
+
+@pytest.mark.parametrize("name", ["degenerate_transforms", "no_planes_nested_spheres", "two_big_meshes", "stress"])
+def test_corner_scenes_and_degenerate_rays(oracle_c, oracle_ref, product_lib, tmp_path, name):
+    """The scenes that tests/test_gpu_pairs.py uses to corner the GPU's (ray, object) pairs -- singular / tiny / huge
+    transforms, the camera inside a sphere, big meshes, objects at the limits of the bounding-sphere rules -- and rays with
+    NaN, infinite, zero, denormal and huge coordinates through intersectScene: the C restatement (what the GPU is compared
+    with) against the reference build, so that also these corners are pinned by the reference's own arithmetic (among them
+    the mesh "hit" at t = FLT_MAX of Ray.inl:171-185 for a direction that overflows to the zero vector)."""
+    import tracer_amd as ta
+    from oracle.pyoracle import Camera as OCam
+    from scene_gen import stress_scene
+    from test_gpu_pairs import CORNER_SCENES
+    data = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tracer_amd", "data")
+    if name == "stress":
+        path = stress_scene(str(tmp_path / "s.scene"), 1)
+    else:
+        path = str(tmp_path / (name + ".scene"))
+        text = CORNER_SCENES[name]
+        open(path, "w").write(text % {"data": data} if "%(data)s" in text else text)
+    w, h = 48, 32
+    sc = ta.Scene(path=path, aspect=(w, h))
+    sr = oracle_ref.scene_wrap(sc.objects_ptr, sc.size); s = oracle_c.scene_wrap(sc.objects_ptr, sc.size)
+    cam = OCam.from_array(sc.camera.as_array())
+    a = oracle_ref.raytrace1(sr, w, h, cam); b = oracle_c.raytrace1(s, w, h, cam, nthreads=4)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    a = oracle_ref.pathtrace(sr, w, h, cam, 3, 1, 2); b = oracle_c.pathtrace(s, w, h, cam, 3, 1, 2, nthreads=4)
+    assert np.array_equal(a["film"], b["film"], equal_nan=True) and a["stats"] == b["stats"]
+    rs = np.random.RandomState(5)
+    n = 600
+    rays = np.concatenate([rs.uniform(-5, 5, (n, 3)), rs.normal(size=(n, 3))], 1).astype(np.float32)
+    rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    vals = np.array([np.nan, np.inf, -np.inf, 0.0, 1e-42, 3e38, -0.0], np.float32)
+    rays[np.arange(n), rs.randint(0, 6, n)] = vals[rs.randint(0, len(vals), n)]
+    rays[::7, 3:] = 0.0
+    for i in range(n):
+        ta_, ida, pa, na = oracle_ref.intersect_scene(sr, rays[i]); tb, idb, pb, nb = oracle_c.intersect_scene(s, rays[i])
+        assert ida == idb and np.array_equal(np.float32(ta_), np.float32(tb), equal_nan=True), (i, rays[i])
+        assert np.array_equal(pa, pb, equal_nan=True) and np.array_equal(na, nb, equal_nan=True), (i, rays[i])
