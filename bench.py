@@ -49,6 +49,12 @@ N_SIMD = 1024                  # 256 CUs x 4
 # whatever the register banks. The numerical contract (-ffp-contract=off) allows no fusing, so the ceiling of this path
 # is one add-or-multiply per lane per 2.5 cycles.
 VALU_ISSUE_CYCLES = 2.5
+# The microarchitecture guide's figure for the same thing (MI355X_MICROARCH.md, constants table: v_fma_f32 with >= 2 waves).
+# Every utilisation below is printed against BOTH constants, labelled.
+VALU_ISSUE_CYCLES_GUIDE = 2.0
+ISSUE_CONSTANTS = (("measured_2.5_cycles_per_wave64_inst", VALU_ISSUE_CYCLES), ("guide_2.0_cycles_per_wave64_inst", VALU_ISSUE_CYCLES_GUIDE))
+ISSUE_CONSTANT_SOURCES = {"measured_2.5_cycles_per_wave64_inst": "tools/micro/issue_rate.hip on this chip (profiles/r02_issue_rate.txt)",
+                          "guide_2.0_cycles_per_wave64_inst": "/opt/skills/guides/MI355X_MICROARCH.md, constants table"}
 C4_W, C4_H, C4_TOTAL_ITERS = 3840, 2160, 512      # config4_strong: an eighth of configs[3]'s 4096 samples per pixel
 
 
@@ -102,43 +108,121 @@ def measured_hbm_traffic(kernel_substr, pattern, whole_call=False):
         return None, None
 
 
+def cpu_processes(kind, n_procs, iters_each):
+    """`n_procs` child processes (oracle/cpu_worker.py: numpy + ctypes only, no GPU), each rendering `iters_each`
+    iterations of the 512x512 workload on a disjoint iteration stride with CPU checker `kind`, all released at one
+    instant. Returns (Mseg/s over the span from the release to the last process's end, segments, seconds)."""
+    import subprocess
+    start_at = time.time() + 4.0                       # interpreter + numpy start-up of the children
+    worker = os.path.join(HERE, "oracle", "cpu_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, worker, kind, str(W), str(H), str(SEED), str(1 + r), str(n_procs),
+                               str(iters_each), repr(start_at)], stdout=subprocess.PIPE, env=env, text=True)
+             for r in range(n_procs)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        if p.returncode != 0:
+            raise RuntimeError(f"cpu_worker exited with {p.returncode}")
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    segs = sum(r["live_segments"] for r in res)
+    t_begin = min(start_at, min(r["t0"] for r in res))   # a process that missed the release started late: counted from the release
+    span = max(r["t1"] for r in res) - t_begin
+    return segs / span / 1e6, segs, span
+
+
 def cpu_baseline():
-    """Time the CPU oracle (plain-C restatement, bit-identical to the reference host build)
-    on this box's host cores over a bounded sample of the same workload."""
+    """The reference's CPU path on this box's host cores over a bounded sample of the same workload.
+
+    value: oracle/_ref/libtracer_ref.so -- the reference's own Ray/Object/Material/Mesh/Utils .inl + GLM compiled by
+    oracle/Makefile, single-threaded by construction -- run as one process per core on disjoint iteration strides
+    (kind "reference"). Beside it the plain-C restatement (bit-identical to that build; OpenMP over pixels and
+    single-threaded). Without oracle/_ref (a tree that never saw /root/reference) the restatement is the value, kind "port"."""
     from oracle.pyoracle import Oracle, available
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     o = Oracle("c")
     o.set_math_mode(Oracle.MATH_LIBM)
     s = o.scene_create(0)
     cam = o.camera_default(W, H)
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    # single thread: 8 iterations of the 512x512 workload
+    # the restatement, single thread: 4 iterations of the 512x512 workload
     t = time.perf_counter()
-    r = o.pathtrace(s, W, H, cam, SEED, 1, 8, want_pbo=False, nthreads=1)
-    dt1 = time.perf_counter() - t
-    v1 = r["stats"]["live_segments"] / dt1 / 1e6
-    # all threads: 48 iterations
-    n_mt = 48
+    r = o.pathtrace(s, W, H, cam, SEED, 1, 4, want_pbo=False, nthreads=1)
+    v1 = r["stats"]["live_segments"] / (time.perf_counter() - t) / 1e6
+    # the restatement, OpenMP over pixels: 32 iterations
+    n_mt = 32
     t = time.perf_counter()
     r = o.pathtrace(s, W, H, cam, SEED, 1, n_mt, want_pbo=False, nthreads=threads)
-    dtm = time.perf_counter() - t
-    vm = r["stats"]["live_segments"] / dtm / 1e6
-    out = {"value": round(vm, 3), "unit": "Mseg/s", "cores": threads, "kind": "port",
-           "sample": f"cornell {W}x{H} mode 2, {n_mt} of {ITERS} iterations, OpenMP over pixels "
-                     f"({threads} threads); single thread: 8 iterations",
-           "single_thread_value": round(v1, 3)}
-    if available("ref"):
-        # the reference's own .inl + GLM host build (single-threaded by construction)
-        R = Oracle("ref")
-        sr = R.scene_create(0, data_dir=os.path.join(HERE, "tracer_amd", "data"))
-        t = time.perf_counter()
-        rr = R.pathtrace(sr, W, H, cam, SEED, 1, 8, want_pbo=False)
-        dtr = time.perf_counter() - t
-        out["reference_host_build_single_thread_value"] = round(rr["stats"]["live_segments"] / dtr / 1e6, 3)
-    return out
+    vm = r["stats"]["live_segments"] / (time.perf_counter() - t) / 1e6
+    port = {"value": round(vm, 3), "unit": "Mseg/s", "cores": threads, "single_thread_value": round(v1, 3),
+            "sample": f"{n_mt} of {ITERS} iterations, OpenMP over pixels ({threads} threads); single thread: 4 iterations"}
+    if not available("ref"):
+        return {"value": port["value"], "unit": "Mseg/s", "cores": threads, "kind": "port",
+                "sample": f"cornell {W}x{H} mode 2, " + port["sample"], "single_thread_value": port["single_thread_value"],
+                "note": "oracle/_ref (the reference host build) is not in this tree: the plain-C restatement was timed"}
+    iters_each = 12
+    v_one, _, _ = cpu_processes("ref", 1, iters_each)
+    v_all, segs, span = cpu_processes("ref", threads, iters_each)
+    return {"value": round(v_all, 3), "unit": "Mseg/s", "cores": threads, "kind": "reference",
+            "sample": f"cornell {W}x{H} mode 2, {threads * iters_each} of {ITERS} iterations: {threads} processes of the reference host "
+                      f"build (oracle/_ref/libtracer_ref.so, single-threaded), {iters_each} iterations each on disjoint iteration strides, "
+                      f"released together; {segs} live segments in {span:.2f} s",
+            "single_thread_value": round(v_one, 3),
+            "parallel_efficiency": round(v_all / (threads * v_one), 3),
+            "port": port}
 
 
-def unfused_peak_tflops(mhz):
-    return 64 * N_SIMD * mhz * 1e6 / VALU_ISSUE_CYCLES / 1e12
+def check_film_against_reference(film, tr):
+    """N == 1, untimed: the film and the LDR image the timed steps left behind -- seed 1, iterations 1..300 of the
+    512x512 Cornell box -- against the sha1 that tools/make_golden.py recorded in tests/golden/meta.json from the
+    reference host build with the kernels' sin/cos/acos/pow interposed (oracle/_ref/libtracer_ref_pm.so; 2.5 minutes on
+    one CPU core, in the build container). Byte for byte; raytrace.cu:162-177 is the running sum it pins."""
+    import hashlib
+    import numpy as np
+    try:
+        meta = json.load(open(os.path.join(HERE, "tests", "golden", "meta.json")))
+        want_film = meta["hashes"]["mode2_512_seed1_film300_pm"]
+        want_ldr = meta["hashes"]["mode2_512_seed1_ldr300_pm"]
+    except (OSError, KeyError, ValueError) as e:
+        return {"ok": None, "note": f"no pinned 300-iteration film in tests/golden/meta.json ({e!r})"}
+    host = film.detach().cpu().numpy()
+    got_film = hashlib.sha1(np.ascontiguousarray(host).tobytes()).hexdigest()
+    got_ldr = hashlib.sha1(np.ascontiguousarray(tr.read_ldr()).tobytes()).hexdigest()
+    mean = [float(x) for x in host.reshape(-1, 3).astype(np.float64).mean(0) / ITERS]
+    return {"against": "reference host build + portable sin/cos/acos/pow (oracle/_ref/libtracer_ref_pm.so), tests/golden/meta.json",
+            "iterations": ITERS, "film_sha1": got_film, "film_sha1_expected": want_film, "ldr_sha1": got_ldr,
+            "ldr_sha1_expected": want_ldr, "film_mean": [round(x, 6) for x in mean],
+            "ok": bool(got_film == want_film and got_ldr == want_ldr)}
+
+
+def unfused_peak_tflops(mhz, issue_cycles=VALU_ISSUE_CYCLES):
+    return 64 * N_SIMD * mhz * 1e6 / issue_cycles / 1e12
+
+
+def issue_utilisation(valu_insts_total, kernel_ms, mhz):
+    """VALU issue utilisation of a launch = the SIMD cycles its wave64 VALU instructions need at the SIMD's best issue rate
+    / the SIMD cycles it ran, for both issue constants."""
+    cycles = kernel_ms * 1e-3 * mhz * 1e6
+    return {name: round(valu_insts_total / N_SIMD * c / cycles, 4) for name, c in ISSUE_CONSTANTS}
+
+
+def mesh_profile():
+    """configs[4]: VALU instructions per (ray, face) pair of k_mesh_brute from the committed PMC pass (tools/pmc_mesh.sh ->
+    profiles/*_mesh_pmc.json, one entry per TRC_OPT_MESH_ACCEL setting), and the reference's flop per pair weighted by where
+    Ray.inl:189-226 leaves (tools/mesh_exit_rates.py -> profiles/*_mesh_exit_rates.json, counted by the oracle once)."""
+    prof, rates = None, None
+    f = latest_profile("*_mesh_pmc.json")
+    if f:
+        try:
+            prof = json.load(open(f)); prof["_file"] = os.path.basename(f)
+        except ValueError:
+            prof = None
+    f = latest_profile("*_mesh_exit_rates.json")
+    if f:
+        try:
+            rates = json.load(open(f)); rates["_file"] = os.path.basename(f)
+        except ValueError:
+            rates = None
+    return prof, rates
 
 
 def timed_render(tr, cam, seed, iters, reps, pipeline=None):
@@ -173,7 +257,7 @@ def extra_configs(ta):
              "roofline": {"bound": "valu", "achieved": round(tf, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(tf / PEAK_FP32_TFLOPS, 4), "flop_per_segment": FLOP_PER_SEGMENT}}
         if mhz:
-            e["roofline"]["frac_unfused_at_clock"] = round(tf / unfused_peak_tflops(mhz), 4)
+            e["roofline"]["frac_unfused_at_clock"] = {name: round(tf / unfused_peak_tflops(mhz, c), 4) for name, c in ISSUE_CONSTANTS}
         tr.close()
         return e
 
@@ -223,16 +307,33 @@ def extra_configs(ta):
         tr.reset_counters(); tr.raytrace1(cam); cnt = tr.counters()
         k_min = min(ms)
         pairs = cnt["tri_tests"]
-        tf = pairs * FLOP_PER_TRI_TEST / (k_min * 1e-3) / 1e12
         e = {"name": f"icosphere 1 310 720 faces, 1024x1024, mode 1: {label}", "config": "BASELINE.json configs[4]", "mesh_accel": accel,
              "frame_ms_min": round(k_min, 4), "frame_ms_median": round(statistics.median(ms), 4),
              "ray_face_pairs": pairs, "value": round(pairs / (k_min * 1e-3) / 1e12, 4), "unit": "T (ray, face) pairs/s"}
         if accel != 1:
-            e["roofline"] = {"bound": "valu", "kernel": "k_mesh_brute", "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(tf / PEAK_FP32_TFLOPS, 4), "flop_per_pair": FLOP_PER_TRI_TEST,
-                             "note": "algorithmic flop of the reference's full test per pair (SURVEY.md 8d) / frame time; the kernel decides "
-                                     "nearly every pair from a conservative bound or from det and bary.x alone, so achieved can exceed the "
-                                     "arithmetic it actually issues"}
+            # The reference leaves its triangle test at Ray.inl:196 / :203 / :208 for almost every pair; the flop of a pair is
+            # the exit-stage costs of SURVEY.md 8(d) (20 / 30 / 46 / 74) weighted by the exit rates the oracle counted on this
+            # frame. The kernel is issue-bound: instructions per pair from the committed PMC pass, clock from its own wavefronts.
+            prof, rates = mesh_profile()
+            rl = {"bound": "valu", "kernel": "k_mesh_brute<%s>" % ("true" if accel == 0 else "false")}
+            if rates:
+                fpp = float(rates["flop_per_pair_weighted"])
+                tf = pairs * fpp / (k_min * 1e-3) / 1e12
+                rl.update({"achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                           "flop_per_pair": round(fpp, 3), "flop_per_pair_source": rates["_file"],
+                           "exit_rates_Ray.inl_196_203_208_none": [round(rates["exit_rates"][k], 8) for k in ("det", "bary_x", "bary_y", "full")],
+                           "note": "reference flop per pair = exit-stage costs 20/30/46/74 (SURVEY.md 8d) weighted by where Ray.inl:189-226 "
+                                   "leaves on this frame; the frame time also holds k_mesh_rays and k_raytrace1 (< 1 %)"})
+            p = (prof or {}).get("by_mesh_accel", {}).get(str(accel))
+            mhz = cnt.get("shader_mhz")
+            if p and mhz:
+                rl["valu_insts_per_64_pairs"] = round(p["valu_insts_per_64_pairs"], 3)      # = per-lane instructions per pair
+                rl["valu_insts_source"] = prof["_file"]
+                rl["valu_insts_profile_matches_run"] = bool(p["pairs_per_frame"] == pairs and prof.get("kernel_source_digest") == kernel_source_digest())
+                rl["shader_mhz"] = round(mhz, 1)
+                rl["valu_issue_utilisation"] = issue_utilisation(p["valu_insts_per_64_pairs"] * pairs / 64.0, k_min, mhz)
+                rl["issue_constants"] = ISSUE_CONSTANT_SOURCES
+            e["roofline"] = rl
         out.append(e)
     tr.close()
     return out
@@ -337,6 +438,8 @@ def main():
     # Untimed self-check of the multi-GPU path: the reduced film must be the one-rank film of the same ITERS x world
     # iterations up to float summation order (1e-5 * sqrt(iterations), relative to the film's scale).
     film_check = None
+    if world == 1:
+        film_check = check_film_against_reference(film, tr)
     if world > 1:
         step(); torch.cuda.synchronize()
         if rank == 0:
@@ -434,7 +537,6 @@ def main():
                 "kernel_ms_median": round(statistics.median(kernel_ms), 4),
                 "flop_per_segment": FLOP_PER_SEGMENT,
                 "flop_per_path": FLOP_PER_PATH,
-                "valu_issue_cycles_per_wave_inst": VALU_ISSUE_CYCLES,
                 "traffic": None,
                 "traffic_source": None,
                 "hbm_algorithmic_GBs": round(seg_per_launch * BYTES_PER_SEGMENT_REF / (k_ms * 1e-3) / 1e9, 2),
@@ -458,18 +560,17 @@ def main():
             # (flagged if that profile's segment count is not this run's), clock and duration live.
             mhz = cnt["shader_mhz"]
             rl["shader_mhz"] = round(mhz, 1)
-            rl["peak_unfused_at_clock"] = round(unfused_peak_tflops(mhz), 2)
-            rl["frac_unfused_at_clock"] = round(achieved / rl["peak_unfused_at_clock"], 4)
+            rl["peak_unfused_at_clock"] = {name: round(unfused_peak_tflops(mhz, c), 2) for name, c in ISSUE_CONSTANTS}
+            rl["frac_unfused_at_clock"] = {name: round(achieved / unfused_peak_tflops(mhz, c), 4) for name, c in ISSUE_CONSTANTS}
+            rl["issue_constants"] = ISSUE_CONSTANT_SOURCES
             per64, prof_segs, src, prof_digest = measured_valu_mix()
             if per64 and args.pipeline != 2:
-                insts_per_simd = per64 * seg_per_launch / 64.0 / N_SIMD
-                cycles = k_ms * 1e-3 * mhz * 1e6
                 rl["valu_insts_per_64_segments"] = round(per64, 1)
                 rl["valu_insts_source"] = src
                 # the profile must be of this workload (segment count) and of these kernel sources (digest recorded by
                 # tools/pmc_summary.py); otherwise the utilisation below mixes two kernels -- flagged, not hidden
                 rl["valu_insts_profile_matches_run"] = bool(prof_segs == int(seg_per_launch) and prof_digest == kernel_source_digest())
-                rl["valu_issue_utilisation"] = round(insts_per_simd * VALU_ISSUE_CYCLES / cycles, 4)
+                rl["valu_issue_utilisation"] = issue_utilisation(per64 * seg_per_launch / 64.0, k_ms, mhz)
         if film_check is not None:
             out["film_check"] = film_check
         if config4 is not None:

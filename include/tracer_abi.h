@@ -142,8 +142,14 @@ int trc_pathtrace(trc_ctx* ctx, const trc_camera* cam, uint64_t seed,
  * and LDR image are those of the context (or trc_bind_film), bit-identical to trc_pathtrace's.
  * Limits: one iteration of the rendered tile must fit the staging area, i.e. at most 5 592 405 pixels per
  * trc_set_tile band (TRC_ERR_UNSUPPORTED beyond; a 3840x2160 frame takes two bands); more iterations than fit
- * are rendered in chunks. All contexts on one GPU share that GPU's array: calls that overlap in time on one GPU
- * (different streams or threads) race -- serialise them. */
+ * are rendered in chunks.
+ * Sharing: all contexts on one GPU share that GPU's array. Calls are ordered against each other ON THE GPU by a
+ * per-device event -- each call's first launch waits for the previous call's last one, whatever context and stream
+ * that ran on -- so contexts with private streams may call back to back without a host synchronisation in between
+ * (tests/test_zz_no_alloc.py). Calls from several host threads are serialised while they enqueue.
+ * Graph capture: a call made while the context's stream is capturing (hipStreamBeginCapture) records memset and
+ * kernel nodes only -- no timing events (trc_last_*_ms then report "nothing rendered") and no guard event: replays of
+ * such a graph must be ordered by the caller against any other use of this entry point on the same GPU. */
 int trc_pathtrace_static(trc_ctx* ctx, const trc_camera* cam, uint64_t seed,
                          uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters);
 
@@ -154,7 +160,10 @@ int trc_pathtrace_static(trc_ctx* ctx, const trc_camera* cam, uint64_t seed,
  * m_nor (zero on a miss). HOST arrays; any output may be NULL; returns after the results have arrived. */
 int trc_intersect_rays(trc_ctx* ctx, const float* rays6, uint32_t n,
                        int32_t* ids, float* ts, float* pos3, float* nor3);
-/* Same with DEVICE arrays, asynchronous on the context's stream (no copies, no waiting). */
+/* Same with DEVICE arrays, asynchronous on the context's stream: no copies and no waiting -- except that a scene with
+ * a MESH of 1024 faces or more keeps a key table and a ray queue of n entries per such mesh, (re)allocated by the first
+ * call and by any call with a larger n than every call before it (hipFree / hipMalloc: a device-wide wait). Query rays
+ * add their triangle tests to trc_counters.tri_tests and nothing to live_segments / paths, which stay what was rendered. */
 int trc_intersect_rays_device(trc_ctx* ctx, const void* rays6_d, uint32_t n,
                               void* ids_d, void* ts_d, void* pos3_d, void* nor3_d);
 /* main.cpp:180-208 in one call: the pixel-corner ray through window position (x, y) of a window_w x window_h

@@ -114,6 +114,12 @@ void  orc_rand3_api(uint64_t seed, uint32_t index, uint32_t iter, uint32_t dim, 
 void  orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t orc_rgb_to_int(float r, float g, float b);
 
+/* C restatement only: exit stages of Ray.inl:189-226 over the (ray, face) pairs of a mode-1 frame (every `step`-th pixel in
+ * x and y) against MESH object `obj`: counts[0..3] = pairs leaving at :196, :203, :208, and running the whole test;
+ * counts[4] = rays past the AABB, counts[5] = rays tried (tools/mesh_exit_rates.py -> the flop weight of configs[4]). */
+void  orc_mesh_exit_histogram(const void* scene, unsigned w, unsigned h, const orc_camera* cam, unsigned obj, unsigned step,
+                              uint64_t counts[6], int nthreads);
+
 /* portable-math unit entry points (oracle/pmath.h); C restatement only */
 void  orc_pm_sincos(float x, float* s, float* c);
 float orc_pm_acos(float x);

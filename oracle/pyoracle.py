@@ -94,6 +94,7 @@ class Oracle:
         L.orc_philox.argtypes = [vp, vp, vp]
         L.orc_rgb_to_int.argtypes = [f32, f32, f32]; L.orc_rgb_to_int.restype = u32
         if kind == "c":
+            L.orc_mesh_exit_histogram.argtypes = [vp, u32, u32, C.POINTER(Camera), u32, u32, vp, i32]
             L.orc_pm_sincos.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
             L.orc_pm_acos.argtypes = [f32]; L.orc_pm_acos.restype = f32
             L.orc_pm_pow.argtypes = [f32, f32]; L.orc_pm_pow.restype = f32
@@ -192,6 +193,13 @@ class Oracle:
         pbo = np.zeros(n, np.uint32)
         self.lib.orc_tonemap(_fp(film), n, float(iters), _fp(pbo))
         return pbo
+
+    def mesh_exit_histogram(self, s, w, h, cam, obj, step, nthreads=1):
+        """(C restatement only) exit stages of Ray.inl:189-226 over the (ray, face) pairs of a sub-sampled mode-1 frame."""
+        counts = np.zeros(6, np.uint64)
+        self.lib.orc_mesh_exit_histogram(s, w, h, C.byref(cam), obj, step, _fp(counts), nthreads)
+        return dict(det=int(counts[0]), bary_x=int(counts[1]), bary_y=int(counts[2]), full=int(counts[3]),
+                    rays_past_aabb=int(counts[4]), rays=int(counts[5]))
 
     # -- unit-level ------------------------------------------------------------------
     def intersect_scene(self, s, ray6):

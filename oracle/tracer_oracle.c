@@ -709,6 +709,60 @@ void orc_raytrace1(const void* sc, unsigned w, unsigned h, const orc_camera* cam
   }
 }
 
+/* Where Ray.inl:189-226 leaves for the (ray, face) pairs of a mode-1 frame: the primary rays of every `step`-th pixel
+ * in x and y (raytrace.cu:40-43) against MESH object `obj`; a ray that passes the AABB (Ray.inl:161-167) meets every
+ * face (:172). counts[0..3] = pairs that return at :196 (|det| < EPS), :203 (bary.x), :208 (bary.y), and pairs that
+ * run the whole test (:209-225); counts[4] = rays that passed the AABB, counts[5] = rays tried. SURVEY.md 8(d) prices
+ * the four stages at 20 / 30 / 46 / 74 flop. */
+void orc_mesh_exit_histogram(const void* sc, unsigned w, unsigned h, const orc_camera* cam, unsigned obj, unsigned step,
+                             uint64_t counts[6], int nthreads) {
+  const Scene* s = (const Scene*)sc;
+  const v3 campos = ldv(cam->campos), A = ldv(cam->A), B = ldv(cam->B), Cc = ldv(cam->C);
+  const Object* o = &s->objs[obj];
+  const Mesh* mesh = o->mesh;
+  uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, pass = 0, tried = 0;
+  if (step == 0) step = 1;
+  const uint nx = (w + step - 1) / step, ny = (h + step - 1) / step;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  #pragma omp parallel for schedule(dynamic, 1) reduction(+: c0, c1, c2, c3, pass, tried)
+  for (uint k = 0; k < nx * ny; ++k) {
+    const uint x = (k % nx) * step, y = (k / nx) * step;
+    v2 uv = { (float)x / w, (float)y / h };
+    Ray wray;
+    wray.pos = add3(add3(add3(campos, Cc), scl3(A, 2.0f * uv.x - 1.0f)), scl3(B, 2.0f * uv.y - 1.0f));
+    wray.dir = normalize3(sub3(wray.pos, campos));
+    const Ray ray = transformRay(wray, &o->matrixi);
+    ++tried;
+    v3 tMin = div3(sub3(mesh->bmin, ray.pos), ray.dir);
+    v3 tMax = div3(sub3(mesh->bmax, ray.pos), ray.dir);
+    v3 t1 = min3(tMin, tMax);
+    v3 t2 = max3(tMin, tMax);
+    float tNear = gmax(gmax(t1.x, t1.y), t1.z);
+    float tFar = gmin(gmin(t2.x, t2.y), t2.z);
+    if (tNear > tFar || tFar < 0.0f) continue;
+    ++pass;
+    for (uint i = 0; i < mesh->numFaces; ++i) {
+      Triangle tri = getTriangle(mesh, i);
+      v3 e1 = sub3(tri.v[1], tri.v[0]);
+      v3 e2 = sub3(tri.v[2], tri.v[0]);
+      v3 pvec = cross3(ray.dir, e2);
+      float det = dot3(e1, pvec);
+      if (gabs(det) < R_EPS) { ++c0; continue; }
+      det = 1.0f / det;
+      v3 tvec = sub3(ray.pos, tri.v[0]);
+      float bx = dot3(tvec, pvec) * det;
+      if (bx < 0.0f || bx > 1.0f) { ++c1; continue; }
+      v3 qvec = cross3(tvec, e1);
+      float by = dot3(ray.dir, qvec) * det;
+      if (by < 0.0f || (bx + by) > 1.0f) { ++c2; continue; }
+      ++c3;
+    }
+  }
+  counts[0] = c0; counts[1] = c1; counts[2] = c2; counts[3] = c3; counts[4] = pass; counts[5] = tried;
+}
+
 static inline v3 rand3v(uint64_t seed, uint32_t index, uint32_t iter, uint32_t dim) {
   float r[3]; orc_rand3(seed, index, iter, dim, r); return V3(r[0], r[1], r[2]);
 }

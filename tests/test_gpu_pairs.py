@@ -122,6 +122,23 @@ object box
   scale 1e19 1 1
   translate 0 3 0
 """,
+    # a MESH scaled below 5e-20: |m_matrixi d|^2 overflows, the object-space direction is the zero vector, and the slab test
+    # of Ray.inl:161-167 passes for every origin that lies below bmax on all three axes -- here the camera and most of the
+    # box: the reference reports the mesh "hit" at distance 0 with t = FLT_MAX and a NaN normal (Ray.inl:171-185), so it
+    # wins every such ray. Its bounding sphere must not cull those pairs (ADVICE r02: bound.h).
+    "tiny_mesh_overflow": "camera fov 30 zoom -13 focal 13 lens 0.2\n" + WALLS + """mesh ico obj %(data)s/icosahedron.obj
+mesh ball sphere
+object ico
+  scale 2e-20
+  translate 6 6 14
+object ico
+  scale 4e-20
+  translate 3 -2 -1
+  material mirr
+object ball
+  scale 3 3 3
+  translate -1 -2 0
+""",
     # two BIG meshes (1280 faces each: their brute-force pass runs ahead of the closest-hit kernel in the launch-per-bounce
     # pipelines and in mode 1, the pairs then read its keys with the owning lane's ray slot) next to a small one
     "two_big_meshes": "camera fov 30 zoom -13 focal 13 lens 0.2\n" + WALLS + """mesh ico obj %(data)s/icosahedron.obj

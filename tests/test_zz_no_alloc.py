@@ -80,3 +80,60 @@ def test_static_scratch_size_limit_and_bands(ta):
         # argument checks as trc_pathtrace's
         with pytest.raises(ta.TracerError):
             tr.pathtrace_static(cam, 3, 0, 1)
+
+
+def test_static_scratch_two_contexts_back_to_back_without_a_host_sync(ta):
+    """Two contexts with private (non-blocking) streams on the one GPU, called alternately from one host thread with
+    nothing in between: both use the GPU's one static array -- task counter and staging -- so without the per-device
+    guard event the second call's memset and samples would land in the first call's. Every film must be
+    the one trc_pathtrace renders alone."""
+    cases = [(768, 512, 0, 21, 1, 12, 1), (512, 512, 1, 22, 1, 16, 1)]      # ~4.7 M and ~4.2 M paths: milliseconds each
+    expected = [_reference_render(ta, w, h, v, ta.camera_default(w, h), seed, first, n, stride)
+                for w, h, v, seed, first, n, stride in cases]
+    ctxs = []
+    for w, h, variant, *_ in cases:
+        sc = ta.Scene(variant)
+        tr = ta.Tracer(w, h)                      # stream=None: a private hipStreamNonBlocking stream each
+        tr.upload_scene(sc.objects_ptr, sc.size)
+        tr._scene = sc
+        ctxs.append(tr)
+    for rounds in range(3):                       # a, b, a, b, a, b -- enqueued faster than they run, no host wait
+        for tr, (w, h, variant, seed, first, n, stride) in zip(ctxs, cases):
+            tr.pathtrace_static(ta.camera_default(w, h), seed, first, n, iter_stride=stride)
+    for tr, (film, ldr) in zip(ctxs, expected):
+        assert tr.read_film().tobytes() == film.tobytes()
+        assert np.array_equal(tr.read_ldr(), ldr)
+    for tr in ctxs:
+        tr.close()
+
+
+def test_static_scratch_entry_point_under_graph_capture(ta):
+    """The advertised use: ONE call captured into a HIP graph (the stream in global capture mode, where hipMalloc and
+    its like are errors), replayed twice, film and LDR against trc_pathtrace's. Capture through torch.cuda.graph on
+    the stream the context launches on."""
+    import torch
+    w, h, variant, seed, n = 640, 384, 1, 31, 6
+    cam = ta.camera_default(w, h)
+    film, ldr = _reference_render(ta, w, h, variant, cam, seed, 1, n)
+    sc = ta.Scene(variant)
+    s = torch.cuda.Stream()
+    with ta.Tracer(w, h, stream=s.cuda_stream) as tr:
+        tr.upload_scene(sc.objects_ptr, sc.size)
+        tr.pathtrace_static(cam, seed, 1, 1)                  # warm-up outside the capture (code objects loaded)
+        tr.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s, capture_error_mode="global"):
+            tr.pathtrace_static(cam, seed, 1, n)
+        with pytest.raises(ta.TracerError, match="nothing rendered"):
+            tr.last_kernel_ms()                               # no timing events were recorded into the capture
+        for _ in range(2):
+            tr.write_film(np.full((w * h, 3), 7.0, np.float32))   # iteration 1 restarts the film: the replay must overwrite this
+            g.replay()
+            torch.cuda.synchronize()
+            assert tr.read_film().tobytes() == film.tobytes()
+            assert np.array_equal(tr.read_ldr(), ldr)
+        # an ordinary call afterwards still works and is timed again
+        tr.pathtrace_static(cam, seed, 1, n)
+        assert tr.read_film().tobytes() == film.tobytes()
+        assert tr.last_kernel_ms() > 0
+        del g

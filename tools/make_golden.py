@@ -43,8 +43,10 @@ def main():
     R = Oracle("ref")
     assert R.name() == "reference-host-build"
     os.makedirs(OUT, exist_ok=True)
-    meta = {"generator": "tools/make_golden.py", "oracle": R.name(),
-            "flags": "g++ -std=c++14 -O2 -ffp-contract=off -DNDEBUG", "hashes": {}}
+    meta = load_meta()          # keys written by the other sections (make_film300) survive
+    meta.update({"generator": "tools/make_golden.py", "oracle": R.name(),
+                 "flags": "g++ -std=c++14 -O2 -ffp-contract=off -DNDEBUG"})
+    meta.setdefault("hashes", {})
 
     # ---- scenes and cameras -------------------------------------------------------------
     scenes = {}
@@ -152,8 +154,51 @@ def main():
     d["rand3_seed5"] = np.stack([R.rand3(5, i * 7919, 3, i % 4) for i in range(64)])
     np.savez_compressed(os.path.join(OUT, "units.npz"), **d)
 
+    save_meta(meta)
+
+
+def load_meta():
+    p = os.path.join(OUT, "meta.json")
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+def save_meta(meta):
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def make_film300(R, P):
+    """The film the benchmark renders -- BASELINE.json configs[1]: default scene, 512x512, seed 1, iterations 1..300,
+    reference RNG reuse (raytrace.cu:162-177: the running sum over all iterations) -- from both reference builds
+    (~2.5 minutes each, single-threaded). Stored: sha1 of the film and of the LDR image of the portable-math build
+    (what the HIP path must equal byte for byte; bench.py checks it after its timed loop), the film's mean, the
+    segment statistics, and -- as data -- the pixels in which the glibc build differs, with its values there, so that a
+    film equal to the portable-math build's can be patched into the glibc build's and checked against ITS sha1."""
+    w = h = 512
+    n = 300
+    out = {}
+    for key, o in (("pm", P), ("glibc", R)):
+        s = o.scene_create(0, 0)
+        out[key] = o.pathtrace(s, w, h, o.camera_default(w, h), 1, 1, n)
+    a, b = out["pm"], out["glibc"]
+    diff = np.nonzero((a["film"] != b["film"]).any(1))[0].astype(np.int32)
+    ldiff = np.nonzero(a["pbo"] != b["pbo"])[0].astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "mode2_film300.npz"), shape=np.array([w, h, 0, 0, 1, n], np.int32),
+                        glibc_diff_idx=diff, glibc_diff_film=b["film"][diff], pm_diff_film=a["film"][diff],
+                        glibc_ldr_diff_idx=ldiff, glibc_ldr_diff_val=b["pbo"][ldiff])
+    meta = load_meta()
+    meta.setdefault("hashes", {})
+    meta["hashes"]["mode2_512_seed1_film300_pm"] = sha(a["film"])
+    meta["hashes"]["mode2_512_seed1_ldr300_pm"] = sha(a["pbo"])
+    meta["hashes"]["mode2_512_seed1_film300_glibc"] = sha(b["film"])
+    meta["hashes"]["mode2_512_seed1_ldr300_glibc"] = sha(b["pbo"])
+    meta["mode2_512_seed1_film300_pm_mean"] = [float(x) for x in (a["film"].astype(np.float64).mean(0) / n)]
+    meta["mode2_512_seed1_300it_stats_pm"] = a["stats"]
+    meta["mode2_512_seed1_300it_stats_glibc"] = b["stats"]
+    meta["mode2_512_seed1_film300_glibc_vs_pm_pixels"] = int(len(diff))
+    save_meta(meta)
+    print("film300:", len(diff), "of", w * h, "pixels differ between the glibc and the portable-math reference builds;",
+          "live segments", a["stats"]["live_segments"], "/", b["stats"]["live_segments"])
 
 
 def make_full(R, P):
@@ -224,13 +269,16 @@ if __name__ == "__main__":
     which = sys.argv[1:]
     if not which:
         main()
-    if not which or "full" in which or "picks" in which:
+    if not which or "full" in which or "picks" in which or "film300" in which:
         Rr = Oracle("ref")
         assert Rr.name() == "reference-host-build"
-        if not which or "full" in which:
+        if not which or "full" in which or "film300" in which:
             Pp = Oracle("ref_pm")
             assert Pp.name() == "reference-host-build+portable-math"
-            make_full(Rr, Pp)
+            if not which or "full" in which:
+                make_full(Rr, Pp)
+            if not which or "film300" in which:
+                make_film300(Rr, Pp)
         if not which or "picks" in which:
             make_picks(Rr)
     for fn in sorted(os.listdir(OUT)):

@@ -26,6 +26,7 @@ cp gpurun_out/pmc_hbm_$TAG/summary.json profiles/${TAG}_hbm.json || exit 1
 PIPE=1 tools/pmc_hbm.sh ${TAG}_compacted > gpurun_out/hbm_${TAG}_compacted.txt 2>&1 || exit 1
 cp gpurun_out/pmc_hbm_${TAG}_compacted/summary.json profiles/${TAG}_compacted_hbm_summary.json || exit 1
 tools/pmc_mesh.sh $TAG > profiles/${TAG}_mesh_brute_stats_pmc.txt 2>&1 || exit 1
+cp gpurun_out/mesh_$TAG/summary.json profiles/${TAG}_mesh_pmc.json || exit 1
 timeout -k 10 400 python3 bench.py > profiles/${TAG}_bench.json 2> gpurun_out/bench_$TAG.err || exit 1
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 python3 -c "

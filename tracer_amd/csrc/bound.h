@@ -40,7 +40,7 @@
 //       (rho + s)^2 - (rho + s/2)^2 >= 0.75 s^2 >= 0.75 * 2^-14 oc2: with |eta| < 2^-16 (checked per lane; a normalised
 //       direction has |eta| <= 3 u, and a lane that fails the check keeps all its pairs) a rejected line is farther
 //       from c than rho + s/2, which is what (1) and (2) need.
-// Objects whose matrix is singular or not finite, with cond > 64 or cond^2 rho > 2^11 get bound_a = +inf: every ray "may
+// Objects whose matrix is singular or not finite, with cond > 64, cond^2 rho > 2^11 or a scale below 1e-18 get bound_a = +inf: every ray "may
 // hit" them. The margins are fat on purpose (s is ~1 % of the scene's extent in the Cornell box: a few more pairs survive).
 // tests/test_gpu_pairs.py compares the pre-test with the exhaustive loop (TRC_PAIRS_CHECK builds) on the reference's scenes,
 // random scenes and scenes built to sit at these limits.
@@ -98,6 +98,11 @@ inline ObjectBound object_bound(const DevObject& o) {
   if (!(lmin > 0.0) || !std::isfinite(lmax)) return out;
   const double smax = std::sqrt(lmax) * (1.0 + 1e-9), smin = std::sqrt(lmin) * (1.0 - 1e-9);
   if (!(smax / smin <= kBoundMaxCond)) return out;
+  // An object scaled below ~5e-20: |m_matrixi d|^2 overflows float for a unit d, Ray.inl:55 then yields the ZERO direction,
+  // and for a MESH the slab test passes whenever the object-space origin lies below bmax on every axis -- the reference
+  // reports a "hit" at distance 0 (Ray.inl:171-185 with t = FLT_MAX; intersect.h keeps that case). Geometry says nothing
+  // about such pairs: no bound (1 / smin is the largest |m_matrixi d| of a unit d).
+  if (!(1.0 / smin <= 1e18)) return out;
   double oc[3] = { 0, 0, 0 }, r = 0.5;
   if (o.mesh_type == REF_CUBE) r = std::sqrt(0.75);
   if (o.mesh_type == REF_MESH) {

@@ -89,6 +89,7 @@ struct BigMeshPass {
   MeshRayQueue q;
   unsigned long long* keys;
   unsigned grid_blocks;
+  DeviceCounters* counters;        // or null: k_mesh_brute adds its wavefronts' clock spans (shader clock of the pass)
 };
 
 inline void set_tile(FrameParams& fp, uint32_t row0, uint32_t rows) {

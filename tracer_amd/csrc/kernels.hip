@@ -201,10 +201,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect_rays(FrameParams fp, const
   if (valid) { const float* r = rays6 + 6ull * i; ray.pos = mk3(r[0], r[1], r[2]); ray.dir = mk3(r[3], r[4], r[5]); }
   uint32_t tt = 0;
   const Hit hit = closest_hit(ray, valid, fp.sc, tt, i, fp.sc.xf);
-  if (counters) {
-    count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
-    count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, valid ? 1ull : 0ull);
-  }
+  // a query ray is not a path segment: live_segments and paths stay what was rendered (bench.py and
+  // trc_multi_last_stats read them as such); its triangle tests were executed and are counted
+  if (counters) count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
   if (!valid) return;
   if (hit_id) hit_id[i] = hit.id;
   if (hit_t) hit_t[i] = hit.t;
@@ -315,8 +314,10 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
                                                       const DevTri* __restrict__ cold, uint32_t tri_count, uint32_t n_tiles,
                                                       uint32_t tiles_per_seg, uint32_t n_segs,
                                                       unsigned long long* __restrict__ keys,
-                                                      const float4* __restrict__ bnd, BvhParams prm, float r_max, float origin_dist) {
+                                                      const float4* __restrict__ bnd, BvhParams prm, float r_max, float origin_dist,
+                                                      DeviceCounters* counters) {
   __shared__ float4 s_tile[kMeshTile * (BOUND ? 1 : 3)];
+  const unsigned long long clk0 = clock64(), ref0 = wall_clock64();
   const uint32_t nq = *q.count;
   const uint32_t n_rb = (nq + kBruteRays - 1) / kBruteRays;
   const uint32_t n_items = n_rb * n_segs;
@@ -460,6 +461,10 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
 #pragma unroll
     for (int r = 0; r < kRaysPerLane; ++r)
       if (best[r] != kKeyNone) atomicMin(&keys[slot[r]], best[r]);
+  }
+  if (counters && lane_id() == 0) {                  // the shader clock this pass ran at (bench.py: issue utilisation)
+    atomicAdd(&counters->bank[blockIdx.x % kCounterBanks].wave_cycles, clock64() - clk0);
+    atomicAdd(&counters->bank[blockIdx.x % kCounterBanks].wave_ref_ticks, wall_clock64() - ref0);
   }
 }
 
@@ -930,7 +935,8 @@ static void launch_big_mesh_passes(const FrameParams& fp, uint32_t n_slots, Path
     hipLaunchKernelGGL((bound ? k_mesh_brute<true> : k_mesh_brute<false>), dim3(bmp.grid_blocks), dim3(kBlock), 0, stream,
                        bmp.q, fp.sc.hot + m.hot_first, fp.sc.tris + m.tri_first, m.tri_count, n_tiles,
                        tiles_per_seg, n_segs, bmp.keys + (size_t)b * fp.sc.key_stride,
-                       reinterpret_cast<const float4*>(fp.sc.tri_bound) + m.hot_first, m.prm, m.r_max, m.origin_dist);
+                       reinterpret_cast<const float4*>(fp.sc.tri_bound) + m.hot_first, m.prm, m.r_max, m.origin_dist,
+                       bmp.counters);
   }
 }
 

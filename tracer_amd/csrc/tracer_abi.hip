@@ -88,6 +88,10 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 void* g_scratch_ptr[kMaxDevices] = {};                         // per device: where `scratch` lives there
+// Per device: recorded behind the last launch of every trc_pathtrace_static call, waited for in front of the next one's
+// first launch. All contexts of a GPU share that GPU's array; with this event two calls on different streams cannot
+// overlap on the GPU even when the host never synchronises between them (a GPU-side dependency: no host wait).
+hipEvent_t g_scratch_event[kMaxDevices] = {};
 
 // `device` must be current. Resolves the device's copy of `scratch` on first use.
 int resolve_scratch(int device, void** out) {
@@ -97,6 +101,7 @@ int resolve_scratch(int device, void** out) {
     void* p = nullptr;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p) return fail(TRC_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    HIP_TRY(hipEventCreateWithFlags(&g_scratch_event[device], hipEventDisableTiming));
     g_scratch_ptr[device] = p;
   }
   *out = g_scratch_ptr[device];
@@ -248,6 +253,7 @@ BigMeshPass big_mesh_pass(const trc_ctx* c) {
   b.bvh = (c->mesh_accel == 1 && c->bvh.size() == c->big.size() && !c->bvh.empty()) ? c->bvh.data() : nullptr;
   b.plain = c->mesh_accel == 2;
   b.q = c->mesh_queue; b.keys = c->mesh_keys; b.grid_blocks = c->brute_blocks;
+  b.counters = c->counters;
   return b;
 }
 
@@ -618,6 +624,7 @@ int trc_intersect_rays_device(trc_ctx* c, const void* rays6_d, uint32_t n, void*
   BigMeshPass bmp = big_mesh_pass(c);
   const BigMeshPass* pass = c->big.empty() ? nullptr : &bmp;
   if (pass) { fp.sc.mesh_keys = c->mesh_keys; fp.sc.key_stride = (uint32_t)c->mesh_slots; }
+  // (query rays are not path segments: k_intersect_rays adds its triangle tests to the counters, nothing else)
   launch_intersect_rays(fp, (const float*)rays6_d, n, (int32_t*)ids_d, (float*)ts_d, (float*)pos3_d, (float*)nor3_d,
                         c->counters, pass, c->stream);
   HIP_TRY(hipGetLastError());
@@ -768,7 +775,21 @@ int trc_pathtrace_static(trc_ctx* c, const trc_camera* cam, uint64_t seed,
   // the addresses the kernels use come from hipGetSymbolAddress (c->scratch_d), never from the array's name
   uint32_t* next_task = reinterpret_cast<uint32_t*>(c->scratch_d);
   float* stage = reinterpret_cast<float*>(c->scratch_d + kScratchHeader);
-  int rc = begin_timing(c); if (rc) return rc;
+  // Under stream capture (hipStreamBeginCapture on this context's stream) the call records kernel and memset nodes
+  // only: the timing events and the cross-context guard event are left out -- an event recorded inside a capture
+  // cannot be queried or waited for outside it -- so trc_last_*_ms report "nothing rendered" afterwards, and replays
+  // of the captured graph are the caller's to order against other users of this GPU's scratch.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  HIP_TRY(hipStreamIsCapturing(c->stream, &cap));
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  // One call at a time enqueues on a device's scratch, and its first launch waits (on the GPU) for the previous
+  // call's last one, whichever context and stream that was on.
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  hipEvent_t guard = g_scratch_event[c->device];
+  if (!capturing) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, guard, 0));
+    int rc = begin_timing(c); if (rc) return rc;
+  }
   for (uint32_t done = 0; done < n_iters; done += chunk_iters) {
     const uint32_t n = (n_iters - done < chunk_iters) ? n_iters - done : chunk_iters;
     // launch_queue zeroes the task counter (stream-ordered) before every launch; k_queue writes every sample of the
@@ -776,9 +797,13 @@ int trc_pathtrace_static(trc_ctx* c, const trc_camera* cam, uint64_t seed,
     launch_queue(fp, iter_first + done * iter_stride, iter_stride, n, c->film, stage, next_task,
                  c->resident_blocks, c->counters, c->stream);
   }
-  HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+  if (!capturing) {
+    HIP_TRY(hipEventRecord(guard, c->stream));                   // the scratch is free again from here on
+    HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+  }
   launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
   HIP_TRY(hipGetLastError());
+  if (capturing) { c->timed = false; return TRC_OK; }
   return end_timing(c);
 }
 
