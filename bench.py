@@ -326,13 +326,20 @@ def extra_configs(ta):
                                    "leaves on this frame; the frame time also holds k_mesh_rays and k_raytrace1 (< 1 %)"})
             p = (prof or {}).get("by_mesh_accel", {}).get(str(accel))
             mhz = cnt.get("shader_mhz")
-            if p and mhz:
+            if p:
+                # instructions AND cycles of the same profiled launch (GRBM_GUI_ACTIVE / 8): self-consistent, whatever the
+                # clock did between this run and that one -- the kernel stands on the issue floor, so a 2 % clock difference
+                # between two runs would otherwise decide on which side of 1.0 the figure lands
                 rl["valu_insts_per_64_pairs"] = round(p["valu_insts_per_64_pairs"], 3)      # = per-lane instructions per pair
+                rl["simd_cycles_per_valu_inst"] = round(p["simd_cycles_per_valu_inst"], 4)
+                rl["valu_issue_utilisation"] = {name: round(c / p["simd_cycles_per_valu_inst"], 4) for name, c in ISSUE_CONSTANTS}
+                rl["issue_constants"] = ISSUE_CONSTANT_SOURCES
                 rl["valu_insts_source"] = prof["_file"]
                 rl["valu_insts_profile_matches_run"] = bool(p["pairs_per_frame"] == pairs and prof.get("kernel_source_digest") == kernel_source_digest())
-                rl["shader_mhz"] = round(mhz, 1)
-                rl["valu_issue_utilisation"] = issue_utilisation(p["valu_insts_per_64_pairs"] * pairs / 64.0, k_min, mhz)
-                rl["issue_constants"] = ISSUE_CONSTANT_SOURCES
+                rl["frame_shader_cycles_in_profile"] = round(p["shader_cycles_per_dispatch"])
+                if mhz:
+                    rl["shader_mhz"] = round(mhz, 1)
+                    rl["frame_shader_cycles_live"] = round(k_min * 1e-3 * mhz * 1e6)
             e["roofline"] = rl
         out.append(e)
     tr.close()

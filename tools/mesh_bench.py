@@ -29,7 +29,7 @@ for rep in range(2):
     tr.reset_counters()
     tr.raytrace1(cam)
     ms = tr.last_kernel_ms(); c = tr.counters()
-    print(f"mode 1 rep {rep}: {ms:.2f} ms, tri_tests {c['tri_tests']:.4g}, {c['tri_tests']/ms/1e6:.2f} Gtests/s", flush=True)
+    print(f"mode 1 rep {rep}: {ms:.2f} ms, tri_tests {c['tri_tests']}, {c['tri_tests']/ms/1e6:.2f} Gtests/s, shader_mhz {c['shader_mhz'] or 0:.1f}", flush=True)
 if iters > 0:
     for rep in range(2):
         tr.reset_counters()

@@ -33,7 +33,7 @@ for a in ("0", "2"):
                 d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                 d["_vgpr"] = int(r["VGPR_Count"]); d["_lds"] = int(r.get("LDS_Block_Size", 0) or 0); d["_name"] = r["Kernel_Name"][:60]
     txt = open("$OUT/a%s.out" % a).read()
-    pairs = [float(x) for x in re.findall(r"mode 1 rep \d+: [\d.]+ ms, tri_tests ([\d.e+]+)", txt)]
+    pairs = [int(x) for x in re.findall(r"mode 1 rep \d+: [\d.]+ ms, tri_tests (\d+)", txt)]
     ms = [float(x) for x in re.findall(r"mode 1 rep \d+: ([\d.]+) ms", txt)]
     n = len(per)
     if not n or not pairs: continue
