@@ -415,10 +415,13 @@ def main():
     film = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)   # torch owns the film so RCCL can reduce it
     tr.bind_film(film.data_ptr())
 
+    reduce_events = []
+
     def step():
         # zero the film, render iterations rank+1, rank+1+world, ... of ITERS x world, ONE sum-reduce to rank 0,
         # display transform there
-        multi.render_partitioned(tr, cam, SEED, ITERS * world, film, rank, world, reducer)
+        multi.render_partitioned(tr, cam, SEED, ITERS * world, film, rank, world, reducer,
+                                 timing=reduce_events if (world > 1 and not rehearsal) else None)
 
     def fence():
         if world > 1:
@@ -428,6 +431,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    reduce_events.clear()
     tr.reset_counters()
     kernel_ms, step_ms = [], []
     t0 = time.perf_counter()
@@ -441,6 +445,27 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     cnt = tr.counters()
+    # the film sum-reduce by itself (N > 1): torch events around dist.reduce on this rank's stream; on the root that is
+    # the wait for the slowest rank plus the transfer, so the minimum over the steps is the closest to the transfer alone
+    reduce_ms = [a.elapsed_time(b) for a, b in reduce_events]
+
+    # N > 1: what ONE GPU does alone on the same per-GPU workload (rank 0, the others wait at the barrier), so that the
+    # line carries its own weak-scaling efficiency = value / (N x that)
+    n1_value = None
+    if world > 1:
+        if rank == 0:
+            k1 = max(5, min(args.steps, 20))
+            for _ in range(2):
+                film.zero_(); tr.pathtrace(cam, SEED, 1, ITERS)
+            torch.cuda.synchronize()
+            tr.reset_counters()
+            t1 = time.perf_counter()
+            for _ in range(k1):
+                film.zero_(); tr.pathtrace(cam, SEED, 1, ITERS)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            n1_value = tr.counters()["live_segments"] / dt1 / 1e6
+        fence()
 
     # Untimed self-check of the multi-GPU path: the reduced film must be the one-rank film of the same ITERS x world
     # iterations up to float summation order (1e-5 * sqrt(iterations), relative to the film's scale).
@@ -578,6 +603,15 @@ def main():
                 # tools/pmc_summary.py); otherwise the utilisation below mixes two kernels -- flagged, not hidden
                 rl["valu_insts_profile_matches_run"] = bool(prof_segs == int(seg_per_launch) and prof_digest == kernel_source_digest())
                 rl["valu_issue_utilisation"] = issue_utilisation(per64 * seg_per_launch / 64.0, k_ms, mhz)
+        if world > 1:
+            out["multi_gpu"] = {"film_reduce_bytes_per_step": 12 * W * H,
+                                "film_reduce_ms_on_root": {"mean": round(sum(reduce_ms) / len(reduce_ms), 4), "min": round(min(reduce_ms), 4),
+                                                           "max": round(max(reduce_ms), 4),
+                                                           "note": "torch events around dist.reduce on rank 0's stream: the wait for the slowest rank plus the transfer"} if reduce_ms else None,
+                                "render_kernel_ms_rank0": round(k_ms, 4),
+                                "one_gpu_value_same_workload": round(n1_value, 2) if n1_value else None,
+                                "efficiency_vs_n1": round(value / (world * n1_value), 4) if n1_value else None,
+                                "efficiency_note": "weak scaling: value / (n_gpus x the rate rank 0 reaches alone on its 300 iterations, measured in this run)"}
         if film_check is not None:
             out["film_check"] = film_check
         if config4 is not None:

@@ -89,12 +89,15 @@ typedef enum trc_option {
   TRC_OPT_RECORD_HITS = 2,  /* 0/1: raytrace1 also stores id/t/pos/nor per pixel (default 1) */
   TRC_OPT_STAGE_MB = 3,     /* TRC_PIPE_QUEUE: staging buffer budget in MiB (default 2048); a call is
                                split into chunks of iterations that fit */
-  TRC_OPT_MESH_ACCEL = 4    /* big meshes in the launch-per-bounce pipelines and mode 1: 0 = every face against every
+  TRC_OPT_MESH_ACCEL = 4,   /* big meshes in the launch-per-bounce pipelines and mode 1: 0 = every face against every
                                ray that passed the AABB, as Ray.inl:172-177 does (default; for meshes of small faces a
                                conservative bounding-sphere test per pair skips the arithmetic of pairs that cannot
                                hit), 1 = bounding-volume hierarchy in front of the same exact triangle test
                                (same hits, same tie rule), 2 = as 0 without the bounding-sphere
                                test (validation) */
+  TRC_OPT_SKIP_TONEMAP = 5  /* 0/1: trc_pathtrace / trc_pathtrace_static leave the LDR image alone (default 0). For the
+                               ranks of a multi-GPU render: only the rank that holds the reduced film needs the display
+                               transform, and it runs it itself with the total iteration count (trc_tonemap) */
 } trc_option;
 
 /* Device-side event counts since the last trc_reset_counters (units of SURVEY.md 8d). */

@@ -52,6 +52,14 @@ int trc_multi_read_ldr(trc_multi* m, uint32_t* bgra);
 /* Wall-clock milliseconds of the last trc_multi_pathtrace (first launch to reduced film), and the live path segments
  * all GPUs traced in it. */
 int trc_multi_last_stats(trc_multi* m, double* ms, uint64_t* live_segments);
+/* Where that time went, so that a scaling curve can explain itself:
+ *   render_ms[r]   (G entries, may be NULL) GPU time of rank r's path kernels, between HIP events on its own stream;
+ *   all_rendered_ms  host clock, from the first launch until every rank's render had finished;
+ *   combine_ms       host clock, from there until GPU 0 held the reduced, tonemapped film: the sum-reduce over RCCL/xGMI
+ *                    (or the same-device sum) plus the display transform. all_rendered_ms + combine_ms = ms of
+ *                    trc_multi_last_stats. During a render the ranks' own display transforms are switched off
+ *                    (TRC_OPT_SKIP_TONEMAP): only GPU 0 runs one, after the reduce. */
+int trc_multi_last_breakdown(trc_multi* m, double* render_ms, double* all_rendered_ms, double* combine_ms);
 
 const char* trc_multi_last_error(void);
 

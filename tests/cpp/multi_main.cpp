@@ -42,6 +42,12 @@ int main(int argc, char** argv) {
   trc_multi_last_stats(m, &ms, &segs);
   printf("gpus %d iterations %u by_tile %d ms %.3f live_segments %llu Mseg/s %.1f\n", trc_multi_size(m), iters, by_tile, ms,
          (unsigned long long)segs, segs / ms / 1e3);
+  std::vector<double> render(devices.size());
+  double all_rendered = 0, combine = 0;
+  if (trc_multi_last_breakdown(m, render.data(), &all_rendered, &combine) != 0) { fprintf(stderr, "breakdown: %s\n", trc_multi_last_error()); return 1; }
+  printf("breakdown all_rendered_ms %.3f combine_ms %.3f render_ms", all_rendered, combine);
+  for (double r : render) printf(" %.3f", r);
+  printf("\n");
   trc_multi_destroy(m);
   trc_scene_free(scene);
   return 0;

@@ -275,3 +275,52 @@ def test_multi_gpu_c_abi(ta, tmp_path):
     film, ldr, _ = run([0, 0, 0], 1)
     assert film.tobytes() == whole.tobytes() and np.array_equal(ldr, whole_ldr)
     tr.close()
+
+
+def test_multi_gpu_c_abi_at_4k_with_four_contexts(ta, tmp_path):
+    """BASELINE.json configs[3]'s shape through the C/C++ multi-GPU layer: 3840x2160, 32 samples, G = 4 contexts (on this
+    box all on the one GPU: the same partition, zeroing, combine and display transform an 8-GPU node runs, with the film sum
+    as a same-device kernel instead of ncclReduce). By sample index: exactly the rank-ordered sum of the four strided partial
+    films, and within 1e-5 sqrt(iterations) of the one-context film; by bands of rows: the one-context film
+    bit for bit. The statistics line must account for the time: per-rank render, all-rendered and combine."""
+    import re
+    exe = os.path.join(REPO, "tests", "cpp", "bin", "multi_main")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(REPO, "tests", "cpp")], check=True)
+    data = os.path.join(REPO, "tracer_amd", "data")
+    w, h, iters, G = 3840, 2160, 32, 4
+    sc = ta.Scene(0)
+    tr = ta.Tracer(w, h)
+    tr.upload_scene(sc.objects_ptr, sc.size)
+    cam = ta.camera_default(w, h)
+    tr.pathtrace(cam, 7, 1, iters)
+    whole, whole_ldr = tr.read_film(), tr.read_ldr()
+    expect = None
+    for r in range(G):
+        tr.reset_film(); tr.pathtrace(cam, 7, r + 1, iters // G, iter_stride=G)
+        part = tr.read_film()
+        expect = part if expect is None else (expect + part).astype(np.float32)
+    for by_tile in (0, 1):
+        out = str(tmp_path / f"k{by_tile}")
+        r = subprocess.run([exe, data, str(w), str(h), str(iters), str(by_tile), out] + ["0"] * G,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        film = np.fromfile(out + ".film", np.float32).reshape(-1, 3)
+        ldr = np.fromfile(out + ".ldr", np.uint32)
+        if by_tile:
+            assert film.tobytes() == whole.tobytes() and np.array_equal(ldr, whole_ldr)
+        else:
+            assert film.tobytes() == expect.tobytes()
+            assert np.abs(film - whole).max() <= 1e-5 * np.sqrt(iters) * whole.max()
+            tr.write_film(expect); tr.tonemap(iters)
+            assert np.array_equal(ldr, tr.read_ldr())
+        m = re.search(r"ms ([\d.]+) live_segments (\d+)", r.stdout)
+        b = re.search(r"breakdown all_rendered_ms ([\d.]+) combine_ms ([\d.]+) render_ms((?: [\d.]+)+)", r.stdout)
+        assert m and b, r.stdout
+        total, all_rendered, combine = float(m.group(1)), float(b.group(1)), float(b.group(2))
+        render = [float(x) for x in b.group(3).split()]
+        assert len(render) == G and all(x > 0 for x in render)
+        assert abs(all_rendered + combine - total) < 0.01 * total + 0.01
+        assert max(render) <= all_rendered * 1.05 + 0.5          # a rank's GPU time fits inside the host's render span
+        assert int(m.group(2)) > 3.5 * w * h * iters             # ~3.7 live segments per path, all ranks together
+    tr.close()

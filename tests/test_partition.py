@@ -54,8 +54,12 @@ class _OracleTracer:
         self.tile = (row0, rows) if rows else None
         self.calls.append(("tile", row0, rows))
 
+    def set_skip_tonemap(self, on):
+        self.skip_tonemap = bool(on)
+        self.calls.append(("skip_tonemap", bool(on)))
+
     def pathtrace(self, cam, seed, iter_first, n_iters, iter_stride=1):
-        self.calls.append(("pathtrace", iter_first, n_iters, iter_stride))
+        self.calls.append(("pathtrace", iter_first, n_iters, iter_stride, getattr(self, "skip_tonemap", False)))
         if self.tile is None:
             self.o.pathtrace(self.s, self.w, self.h, cam, seed, iter_first, n_iters, iter_stride=iter_stride,
                              film=self.film, want_pbo=False)
@@ -87,6 +91,8 @@ def _worker(rank, world, port, total_iters, w, h, seed, out_dir, by_tile=False):
     assert names.index("sync") > names.index("pathtrace")           # the render is awaited before the reduce
     assert (("tonemap", total_iters) in tr.calls) == (rank == 0)
     assert tr.tile is None                                          # the tile is always reset
+    # the ranks' own display transforms are off during the render (rank 0 tonemaps the REDUCED film) and back on afterwards
+    assert all(c[4] for c in tr.calls if c[0] == "pathtrace") and tr.skip_tonemap is False
     if rank == 0:
         np.save(os.path.join(out_dir, "film.npy"), film.numpy().reshape(w * h, 3))
     dist.barrier()

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RNG_REFERENCE, RNG_DECORRELATED = 0, 1
 PIPE_WAVEFRONT, PIPE_COMPACTED, PIPE_FUSED, PIPE_QUEUE, PIPE_AUTO = 0, 1, 2, 3, 4
-OPT_RNG_MODE, OPT_PIPELINE, OPT_RECORD_HITS, OPT_STAGE_MB, OPT_MESH_ACCEL = 0, 1, 2, 3, 4
+OPT_RNG_MODE, OPT_PIPELINE, OPT_RECORD_HITS, OPT_STAGE_MB, OPT_MESH_ACCEL, OPT_SKIP_TONEMAP = 0, 1, 2, 3, 4, 5
 
 # every symbol include/tracer_abi.h declares
 ABI_SYMBOLS = [
@@ -201,6 +201,10 @@ class Tracer:
 
     def set_stage_mb(self, mb):
         self._check(self.L.trc_set_option(self.ctx, OPT_STAGE_MB, int(mb)))
+
+    def set_skip_tonemap(self, on):
+        """pathtrace calls leave the LDR image alone (ranks of a multi-GPU render: the root tonemaps after the reduce)."""
+        self._check(self.L.trc_set_option(self.ctx, OPT_SKIP_TONEMAP, int(bool(on))))
 
     def set_record_hits(self, on):
         self._check(self.L.trc_set_option(self.ctx, OPT_RECORD_HITS, int(bool(on))))

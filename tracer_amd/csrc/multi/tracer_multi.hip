@@ -32,7 +32,9 @@ struct trc_multi {
   std::vector<hipStream_t> streams;
   std::vector<ncclComm_t> comms;      // empty: same-device mode (no RCCL)
   uint32_t w = 0, h = 0;
-  double last_ms = 0.0;
+  std::vector<hipEvent_t> rendered;   // per rank: recorded on its stream behind its render
+  double last_ms = 0.0, last_all_rendered_ms = 0.0, last_combine_ms = 0.0;
+  std::vector<double> last_render_ms;
   uint64_t last_segments = 0;
 };
 
@@ -63,6 +65,9 @@ int trc_multi_create(const int* devices, int n_devices, uint32_t width, uint32_t
       trc_ctx* c = nullptr;
       TRC_TRY(trc_create(devices[r], width, height, s, &c));
       m->ctx.push_back(c);
+      hipEvent_t e = nullptr;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      m->rendered.push_back(e);
     }
     // (TRC_MULTI_RCCL_SINGLE=1: a communicator and the ncclReduce call for ONE GPU too -- a one-rank reduce is a no-op
     //  copy -- so that a one-GPU box can exercise the RCCL path end to end)
@@ -82,6 +87,7 @@ int trc_multi_destroy(trc_multi* m) {
   if (!m) return TRC_OK;
   for (ncclComm_t c : m->comms) if (c) (void)ncclCommDestroy(c);
   for (trc_ctx* c : m->ctx) (void)trc_destroy(c);
+  for (size_t r = 0; r < m->rendered.size(); ++r) { (void)hipSetDevice(m->devices[r]); (void)hipEventDestroy(m->rendered[r]); }
   for (size_t r = 0; r < m->streams.size(); ++r) { (void)hipSetDevice(m->devices[r]); (void)hipStreamDestroy(m->streams[r]); }
   delete m;
   return TRC_OK;
@@ -113,27 +119,34 @@ int trc_multi_pathtrace(trc_multi* m, const trc_camera* cam, uint64_t seed, uint
   if (total_iters == 0) return fail(TRC_ERR_INVALID, "trc_multi_pathtrace: no iterations");
   const uint32_t G = (uint32_t)m->ctx.size();
   const size_t n_floats = 3ull * m->w * m->h;
-  for (trc_ctx* c : m->ctx) TRC_TRY(trc_reset_counters(c));
+  const bool combine = G > 1 || !m->comms.empty();
+  // a rank's own display transform is wasted work when a combine follows: GPU 0 runs the one that counts, after the reduce
+  for (trc_ctx* c : m->ctx) { TRC_TRY(trc_reset_counters(c)); TRC_TRY(trc_set_option(c, TRC_OPT_SKIP_TONEMAP, combine ? 1 : 0)); }
+  auto restore = [&]() { for (trc_ctx* c : m->ctx) (void)trc_set_option(c, TRC_OPT_SKIP_TONEMAP, 0); };
+  std::vector<char> rendered_something(G, 0);
   const auto t0 = std::chrono::steady_clock::now();
   // every GPU: zero its film, render its share; all launches are asynchronous on the context's stream
   for (uint32_t r = 0; r < G; ++r) {
     trc_ctx* c = m->ctx[r];
-    TRC_TRY(trc_reset_film(c));
-    if (by_tile) {
+    int rc = trc_reset_film(c);
+    if (rc == TRC_OK && by_tile) {
       const uint32_t y0 = (uint32_t)((uint64_t)m->h * r / G), y1 = (uint32_t)((uint64_t)m->h * (r + 1) / G);
       if (y1 > y0) {
-        TRC_TRY(trc_set_tile(c, y0, y1 - y0));
-        const int rc = trc_pathtrace(c, cam, seed, 1, 1, total_iters);
+        rc = trc_set_tile(c, y0, y1 - y0);
+        if (rc == TRC_OK) { rc = trc_pathtrace(c, cam, seed, 1, 1, total_iters); rendered_something[r] = 1; }
         (void)trc_set_tile(c, 0, 0);
-        if (rc != TRC_OK) return fail(rc, std::string("trc_pathtrace: ") + trc_last_error_string());
       }
-    } else {
+    } else if (rc == TRC_OK) {
       const uint32_t count = total_iters > r ? (total_iters - r + G - 1) / G : 0;      // iterations r+1, r+1+G, ...
-      if (count) TRC_TRY(trc_pathtrace(c, cam, seed, r + 1, G, count));
+      if (count) { rc = trc_pathtrace(c, cam, seed, r + 1, G, count); rendered_something[r] = 1; }
     }
+    if (rc != TRC_OK) { restore(); return fail(rc, std::string("rank ") + std::to_string(r) + ": " + trc_last_error_string()); }
+    (void)hipSetDevice(m->devices[r]);
+    HIP_TRY(hipEventRecord(m->rendered[r], m->streams[r]));
   }
+  restore();
   // the path's one exchange: sum of the films onto GPU 0
-  if (G > 1 || !m->comms.empty()) {
+  if (combine) {
     std::vector<void*> film(G);
     for (uint32_t r = 0; r < G; ++r) TRC_TRY(trc_film_device_ptr(m->ctx[r], &film[r]));
     if (!m->comms.empty()) {
@@ -144,9 +157,10 @@ int trc_multi_pathtrace(trc_multi* m, const trc_camera* cam, uint64_t seed, uint
       }
       NCCL_TRY(ncclGroupEnd());
     } else {
-      // same-device testing mode: the contexts share one GPU; wait for the other renders, add them on stream 0 in order
+      // same-device testing mode: the contexts share one GPU; stream 0 waits (on the GPU) for the other renders and adds
+      // their films in rank order
       HIP_TRY(hipSetDevice(m->devices[0]));
-      for (uint32_t r = 1; r < G; ++r) TRC_TRY(trc_synchronize(m->ctx[r]));
+      for (uint32_t r = 1; r < G; ++r) HIP_TRY(hipStreamWaitEvent(m->streams[0], m->rendered[r], 0));
       for (uint32_t r = 1; r < G; ++r)
         hipLaunchKernelGGL(k_film_add, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, m->streams[0],
                            (float*)film[0], (const float*)film[r], n_floats);
@@ -154,10 +168,21 @@ int trc_multi_pathtrace(trc_multi* m, const trc_camera* cam, uint64_t seed, uint
     }
     TRC_TRY(trc_tonemap(m->ctx[0], (float)total_iters));
   }
+  // host clock: when every rank's render had finished, then when GPU 0 held the result
+  for (uint32_t r = 0; r < G; ++r) { (void)hipSetDevice(m->devices[r]); HIP_TRY(hipEventSynchronize(m->rendered[r])); }
+  const auto t1 = std::chrono::steady_clock::now();
   for (trc_ctx* c : m->ctx) TRC_TRY(trc_synchronize(c));
-  m->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  const auto t2 = std::chrono::steady_clock::now();
+  m->last_all_rendered_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  m->last_combine_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  m->last_ms = std::chrono::duration<double, std::milli>(t2 - t0).count();
   m->last_segments = 0;
-  for (trc_ctx* c : m->ctx) { trc_counters k; TRC_TRY(trc_get_counters(c, &k)); m->last_segments += k.live_segments; }
+  m->last_render_ms.assign(G, 0.0);
+  for (uint32_t r = 0; r < G; ++r) {
+    trc_counters k; TRC_TRY(trc_get_counters(m->ctx[r], &k)); m->last_segments += k.live_segments;
+    float ms = 0.0f;
+    if (rendered_something[r]) { TRC_TRY(trc_last_kernel_ms(m->ctx[r], &ms)); m->last_render_ms[r] = ms; }
+  }
   return TRC_OK;
 }
 
@@ -177,6 +202,14 @@ int trc_multi_last_stats(trc_multi* m, double* ms, uint64_t* live_segments) {
   if (!m) return fail(TRC_ERR_INVALID, "null trc_multi");
   if (ms) *ms = m->last_ms;
   if (live_segments) *live_segments = m->last_segments;
+  return TRC_OK;
+}
+
+int trc_multi_last_breakdown(trc_multi* m, double* render_ms, double* all_rendered_ms, double* combine_ms) {
+  if (!m) return fail(TRC_ERR_INVALID, "null trc_multi");
+  if (render_ms) for (size_t r = 0; r < m->ctx.size(); ++r) render_ms[r] = r < m->last_render_ms.size() ? m->last_render_ms[r] : 0.0;
+  if (all_rendered_ms) *all_rendered_ms = m->last_all_rendered_ms;
+  if (combine_ms) *combine_ms = m->last_combine_ms;
   return TRC_OK;
 }
 

@@ -122,6 +122,7 @@ struct trc_ctx {
   int stage_mb = 2048;
   int record_hits = 1;
   int mesh_accel = 0;                      // TRC_OPT_MESH_ACCEL
+  int skip_tonemap = 0;                    // TRC_OPT_SKIP_TONEMAP
   uint32_t tile_row0 = 0, tile_rows = 0;   // trc_set_tile; rows == 0: the whole image
 
   // scene: one device allocation [xforms | cube extras | mesh extras | materials | triangles]
@@ -547,6 +548,8 @@ int trc_set_option(trc_ctx* c, int option, int value) {
     case TRC_OPT_STAGE_MB:
       if (value < 1) return fail(TRC_ERR_INVALID, "bad staging budget");
       c->stage_mb = value; return TRC_OK;
+    case TRC_OPT_SKIP_TONEMAP:
+      c->skip_tonemap = value ? 1 : 0; return TRC_OK;
     default: return fail(TRC_ERR_INVALID, "unknown option");
   }
 }
@@ -742,7 +745,7 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
     }
   }
   HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
-  launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
+  if (!c->skip_tonemap) launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
   HIP_TRY(hipGetLastError());
   return end_timing(c);
 }
@@ -801,7 +804,7 @@ int trc_pathtrace_static(trc_ctx* c, const trc_camera* cam, uint64_t seed,
     HIP_TRY(hipEventRecord(guard, c->stream));                   // the scratch is free again from here on
     HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
   }
-  launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
+  if (!c->skip_tonemap) launch_tonemap(c->film, c->npix, (float)last_iter, c->ldr, c->stream);
   HIP_TRY(hipGetLastError());
   if (capturing) { c->timed = false; return TRC_OK; }
   return end_timing(c);

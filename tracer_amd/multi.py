@@ -50,7 +50,7 @@ def _shares_torch_stream(tracer, film):
     return bool(handle) and handle == torch.cuda.current_stream(film.device).cuda_stream
 
 
-def render_partitioned(tracer, cam, seed, total_iters, film, rank, world, dist, by_tile=False, height=None):
+def render_partitioned(tracer, cam, seed, total_iters, film, rank, world, dist, by_tile=False, height=None, timing=None):
     """Render this rank's share of `total_iters` iterations into `film` (a torch tensor bound to
     the tracer with Tracer.bind_film), sum-reduce to rank 0 and tonemap there. The share is a set of
     sample indices (default) or, with by_tile, a band of image rows rendered for every iteration; the
@@ -59,26 +59,49 @@ def render_partitioned(tracer, cam, seed, total_iters, film, rank, world, dist, 
     Ordering. film.zero_() and the reduce run on torch's current stream, the render and the tonemap on the
     tracer's. Unless the two are the same stream (Tracer(stream=torch_stream.cuda_stream) with that stream
     current) the function orders them itself: it waits for the zero before rendering, for the render before
-    the reduce, and for the reduce before the tonemap."""
+    the reduce, and for the reduce before the tonemap.
+
+    With more than one rank the ranks' own display transforms are switched off for the render (only rank 0 needs an
+    LDR image, and only of the reduced film: it runs the transform after the reduce).
+
+    timing: an optional list; for a GPU film a pair of torch events recorded around the reduce on torch's current stream
+    is appended to it (the caller reads elapsed_time after synchronising: on the root this is the wait for the slowest
+    rank plus the transfer)."""
     same = _shares_torch_stream(tracer, film)
     film.zero_()
     if not same:
         _torch_stream_sync(film)
-    if by_tile:
-        y0, y1 = tile_rows(tracer.h if height is None else height, rank, world)
-        if y1 > y0:
-            tracer.set_tile(y0, y1 - y0)
-            try:
-                tracer.pathtrace(cam, seed, 1, total_iters)
-            finally:
-                tracer.set_tile(0, 0)
-    else:
-        first, stride, count = rank_iterations(total_iters, rank, world)
-        if count:
-            tracer.pathtrace(cam, seed, first, count, iter_stride=stride)
+    multi = world > 1 and hasattr(tracer, "set_skip_tonemap")
+    if multi:
+        tracer.set_skip_tonemap(True)
+    try:
+        if by_tile:
+            y0, y1 = tile_rows(tracer.h if height is None else height, rank, world)
+            if y1 > y0:
+                tracer.set_tile(y0, y1 - y0)
+                try:
+                    tracer.pathtrace(cam, seed, 1, total_iters)
+                finally:
+                    tracer.set_tile(0, 0)
+        else:
+            first, stride, count = rank_iterations(total_iters, rank, world)
+            if count:
+                tracer.pathtrace(cam, seed, first, count, iter_stride=stride)
+    finally:
+        if multi:
+            tracer.set_skip_tonemap(False)
     if not same:
         tracer.synchronize()
+    events = None
+    if timing is not None and getattr(film, "is_cuda", False) and world > 1:
+        import torch
+        events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        events[0].record(torch.cuda.current_stream(film.device))
     reduce_film(film, dist, 0)
+    if events is not None:
+        import torch
+        events[1].record(torch.cuda.current_stream(film.device))
+        timing.append(events)
     if rank == 0 and world > 1:          # (a single rank's pathtrace call has already run the display transform)
         if not same:
             _torch_stream_sync(film)
