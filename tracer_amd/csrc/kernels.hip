@@ -303,12 +303,17 @@ constexpr uint32_t kBruteRays = kBlock * kRaysPerLane;   // rays per work item
 // BOUND: a bounding-sphere pre-test in front of all that (meshes whose faces are small against the mesh, BigMesh::
 // use_bound). The LDS tile then holds one float4 per face -- the centre of its bounding sphere -- and a pair goes
 // on to the arithmetic above (its HotTri record read from memory) only if the ray's line passes within
-//   thr = (r_max + pad(o)) * 1.00001 + 1e-6 * (reach + |mesh centre|)
+//   thr = (r_max + pad(o)) * 1.00001 + 2e-6 * (reach + |mesh centre|)
 // of the centre: r_max + pad(o) is as far as the line of a pair that the floating-point test accepts can be
-// (bvh.h: mesh_bound_spheres), and the second term covers the rounding of |(c - o) x d| itself (at most
-// 7 * 2^-24 * (reach + |mesh centre|): three roundings per component of the cross product on operands no larger
-// than |c - o| <= reach, plus the rounding of c - o on coordinates no larger than reach + |mesh centre|).
-// 18 instead of 26 VALU instructions per pair and one LDS read per face instead of three.
+// (bvh.h: mesh_bound_spheres), and the second term covers the rounding of the distance itself. The distance vector is
+//   w = (c - o) x d = c x d - m,   m = o x d  (the ray's moment about the object-space origin, formed once per ray),
+// evaluated as two fused multiply-adds per component (this arithmetic is the pre-test's own, not the reference's: it
+// only has to be accurate): m carries <= 2^-23 |o| of rounding per component, the two fma of a component one rounding
+// each on magnitudes <= |c| + |o|, so |w - w_true| <= sqrt(3) * 2^-22 (|c| + |o|) <= 8.3e-7 (reach + |mesh centre|)
+// (|o| <= reach + |mesh centre|, |c| <= |mesh centre| + radius <= |mesh centre| + reach); the factor 1.00001 takes the
+// three roundings of w.w and |d|^2 = 1 +- 2^-22.
+// 10 VALU instructions per pair (round 2: 18, the cross product of c - o unfused; 26 for the exact arithmetic) and one
+// LDS read per face instead of three.
 template <bool BOUND>
 __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const HotTri* __restrict__ hot,
                                                       const DevTri* __restrict__ cold, uint32_t tri_count, uint32_t n_tiles,
@@ -337,15 +342,19 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
       if (valid[r]) { slot[r] = q.slot[j]; o[r] = mk3(q.ox[j], q.oy[j], q.oz[j]); d[r] = mk3(q.dx[j], q.dy[j], q.dz[j]); }
     }
     float thr2[kRaysPerLane];        // BOUND: squared pre-test distance of this lane's rays; -1 = no ray, every pair certain
+    f3 mom[kRaysPerLane];            // BOUND: o x d
 #pragma unroll
     for (int r = 0; r < kRaysPerLane; ++r) {
       thr2[r] = -1.0f;
+      mom[r] = splat3(0.0f);
       if (BOUND && valid[r]) {
         const f3 oc = o[r] - prm.centre;
         const float reach = sqrtf(dot(oc, oc)) + prm.radius;
         const float pad = kPadScale * prm.max_edge * prm.max_edge * (reach + prm.max_edge);
-        const float thr = (r_max + pad) * 1.00001f + 1e-6f * (reach + origin_dist);
+        const float thr = (r_max + pad) * 1.00001f + 2e-6f * (reach + origin_dist);
         thr2[r] = thr * thr;
+        mom[r] = mk3(__builtin_fmaf(o[r].y, d[r].z, -(o[r].z * d[r].y)), __builtin_fmaf(o[r].z, d[r].x, -(o[r].x * d[r].z)),
+                     __builtin_fmaf(o[r].x, d[r].y, -(o[r].y * d[r].x)));
       }
     }
     const uint32_t tile0 = seg * tiles_per_seg;
@@ -428,24 +437,38 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
         }
       };
       if (BOUND) {
-        // the pre-test; !(n > thr2) as "unordered or <=", so that a NaN keeps the pair
-        auto pre = [&](const float4& c, uint32_t k) {
+        // the pre-test; !(n > thr2) as "unordered or <=", so that a NaN keeps the pair. The lanes (of either ray) that
+        // cannot rule face centre c out:
+        auto open_of = [&](const float4& c) -> lmask {
           lmask open = 0ull;
 #pragma unroll
           for (int r = 0; r < kRaysPerLane; ++r) {
-            const f3 w = cross(mk3(c.x, c.y, c.z) - o[r], d[r]);
-            open |= TRC_FCMP(dot(w, w), thr2[r], 13 /* FCMP_ULE */);
+            // w = c x d - m: two fma per component, then w.w with two more
+            const float wx = __builtin_fmaf(c.y, d[r].z, -__builtin_fmaf(c.z, d[r].y, mom[r].x));
+            const float wy = __builtin_fmaf(c.z, d[r].x, -__builtin_fmaf(c.x, d[r].z, mom[r].y));
+            const float wz = __builtin_fmaf(c.x, d[r].y, -__builtin_fmaf(c.y, d[r].x, mom[r].z));
+            const float n = __builtin_fmaf(wz, wz, __builtin_fmaf(wy, wy, wx * wx));
+            open |= TRC_FCMP(n, thr2[r], 13 /* FCMP_ULE */);
           }
-          if (__builtin_expect(open == 0ull, 1)) return;
+          return open;           // (one comparison for both rays through v_min was measured: no faster, 78.1 against 77.9 ms)
+        };
+        auto exact = [&](uint32_t k) {
           const size_t rec = ((size_t)tile * kMeshTile + k) * 3;           // wave-uniform address
           test(src[rec], src[rec + 1], src[rec + 2], k);
         };
-        float4 c0 = s_tile[0], c1;
-        for (uint32_t k = 0; k < kMeshTile; k += 2) {
-          c1 = s_tile[k + 1];
-          pre(c0, k);
-          if (k + 2 < kMeshTile) c0 = s_tile[k + 2];
-          pre(c1, k + 1);
+        // four faces per trip: one decision (and one branch) for all of them -- nearly always "none is open";
+        // the next four centres are on their way from LDS meanwhile
+        static_assert(kMeshTile % 4 == 0, "four faces per trip");
+        float4 c0 = s_tile[0], c1 = s_tile[1], c2 = s_tile[2], c3 = s_tile[3];
+        for (uint32_t k = 0; k < kMeshTile; k += 4) {
+          const float4 a0 = c0, a1 = c1, a2 = c2, a3 = c3;
+          if (k + 4 < kMeshTile) { c0 = s_tile[k + 4]; c1 = s_tile[k + 5]; c2 = s_tile[k + 6]; c3 = s_tile[k + 7]; }
+          const lmask o0 = open_of(a0), o1 = open_of(a1), o2 = open_of(a2), o3 = open_of(a3);
+          if (__builtin_expect((o0 | o1 | o2 | o3) == 0ull, 1)) continue;
+          if (o0) exact(k);
+          if (o1) exact(k + 1);
+          if (o2) exact(k + 2);
+          if (o3) exact(k + 3);
         }
         continue;
       }
