@@ -699,14 +699,16 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
   const bool wave = pipeline == TRC_PIPE_WAVEFRONT || pipeline == TRC_PIPE_COMPACTED;
   // Iterations per launch sequence (work queue and wavefront pipelines): what fits the staging budget, at
   // least one; paths per chunk < 2^31; the wavefront pipelines also keep 40-80 B of ray state per path, so
-  // they stop at 2^25 paths per chunk (measured optimum: 2^24 .. 2^25).
+  // they stop at 2^27 paths per chunk (10.7 GB of ray state).
   uint32_t chunk_iters = 0;
   if (pipeline == TRC_PIPE_QUEUE || wave) {
     const size_t per_iter = 3ull * fp.ntile;
     size_t fit = ((size_t)c->stage_mb << 20) / (sizeof(float) * per_iter);
     const size_t cap31 = 0x7FFFFFFFull / fp.ntile;
     if (fit > cap31) fit = cap31;
-    if (wave && fit > (size_t(1) << 25) / fp.ntile) fit = (size_t(1) << 25) / fp.ntile;
+    // (round 3, headline workload through the compacted pipeline: chunks of 2^23 / 24 / 25 / 26 / 27 path slots take
+    //  13.4 / 11.7 / 11.0 / 10.7 / 10.3 ms -- every launch sequence ends in a tail and 288 GB hold the 80 bytes per slot easily)
+    if (wave && fit > (size_t(1) << 27) / fp.ntile) fit = (size_t(1) << 27) / fp.ntile;
     if (fit < 1) fit = 1;
     chunk_iters = (uint32_t)(fit < n_iters ? fit : n_iters);
     const size_t need = per_iter * chunk_iters;
