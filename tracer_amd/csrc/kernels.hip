@@ -584,16 +584,29 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
 #ifndef TRC_BOUNCE_BPR
 #define TRC_BOUNCE_BPR 64
 #endif
+// All of k_bounce's arguments as one struct (FrameParams first: kernarg_params()), for the same reason as k_queue's: a loop
+// that keeps 68 dwords of FrameParams, twenty state pointers and the rest in SGPRs leaves too few for its body, and the
+// overflow lives in VGPR lanes -- round 2's k_bounce had 75-90 spilled SGPRs (every reload a v_readlane) and ran the same
+// arithmetic a quarter slower than k_queue even where it loads no state at all. Each part of a trip now reads the fields
+// it needs from the kernel-argument segment right there (s_load, scalar cache).
+struct BounceArgs {
+  FrameParams fp;
+  uint32_t iter_first, iter_stride, n_slots, bpr;
+  int depth;
+  PathState cur, next;
+  const uint32_t* count_in; uint32_t* count_out;
+  float* stage; DeviceCounters* counters;
+};
+static_assert(offsetof(BounceArgs, fp) == 0, "kernarg_params() reads the FrameParams at offset 0 of the kernel-argument segment");
+__device__ __forceinline__ const BounceArgs* kernarg_bounce() { return reinterpret_cast<const BounceArgs*>(kernarg_params()); }
+
 template <bool COMPACT, bool LDS_GATHER, bool FIRST>
-__global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(FrameParams fp, uint32_t iter_first, uint32_t iter_stride,
-                                                  uint32_t n_slots, int depth, uint32_t bpr,
-                                                  PathState cur, PathState next,
-                                                  const uint32_t* __restrict__ count_in,
-                                                  uint32_t* __restrict__ count_out,
-                                                  float* __restrict__ stage, DeviceCounters* counters) {
-  const uint32_t cap = region_cap(n_slots);
+__global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs a) {
+  const FrameParams& fp = a.fp;
+  const uint32_t cap = region_cap(a.n_slots);
+  const uint32_t bpr = a.bpr;
   const uint32_t p = blockIdx.x / bpr;                                // this workgroup's region
-  const uint32_t n_in = (COMPACT && !FIRST) ? count_in[p * kCountStride] : region_initial(n_slots, cap, p);
+  const uint32_t n_in = (COMPACT && !FIRST) ? a.count_in[p * kCountStride] : region_initial(a.n_slots, cap, p);
   uint32_t first = (blockIdx.x - p * bpr) * kBlock;
   if (first >= n_in) return;                                          // whole block past its region's queue
   __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];              // as in k_queue: table of the held candidates' gathers
@@ -602,65 +615,86 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(FrameParams
     for (uint32_t k = threadIdx.x; k < n_dw; k += kBlock) ((uint32_t*)s_xf)[k] = ((const uint32_t*)fp.sc.xf)[k];
     __syncthreads();
   }
+  const uint32_t region_base = p * cap;
+  const uint32_t step = bpr * kBlock;
+  const int depth = a.depth;
   uint32_t tt = 0, n_live = 0, n_paths = 0;
-  for (; first < n_in; first += bpr * kBlock) {
-  const uint32_t i = p * cap + first + threadIdx.x;
-  const bool in_queue = first + threadIdx.x < n_in;
-  const int32_t task = !in_queue ? -1 : FIRST ? (int32_t)i : cur.pixel[i];     // initially slot == task (raytrace.cu:101)
-  const bool active = task >= 0;                                      // raytrace.cu:119-124
-  uint32_t s = 0;
-  const uint32_t itk = udivmod(active ? (uint32_t)task : 0u, fp.div_tile, s);
-  const uint32_t pixel = fp.pix0 + s, iter = iter_first + itk * iter_stride;
-  Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
-  f3 col = splat3(0.0f);
-  if (FIRST) {
-    ray = camera_sample(fp, pixel, iter);                             // initBuffersKernel, raytrace.cu:72-96
-    col = splat3(1.0f);                                               // raytrace.cu:99
-    n_paths += active ? 1u : 0u;
-  } else if (active) {
-    ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]);
-    ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
-    col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
-  }
-  const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true, false, true)
-                             : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i);
-  const bool cont = (res == STEP_CONTINUE);
-  if (res == STEP_LIGHT || res == STEP_BLACK) {
-    // Every path writes its sample when it ends -- the radiance it carried to the light, or the zero that bounce_step()
-    // left in `col` for a miss or the depth cap -- exactly once per slot of the chunk, as k_queue does: the staging buffer
-    // needs no clearing (round 2 zero-filled 0.9 GB per 300 iterations here and wrote only at the light).
-    float* dst = stage + 3ull * (uint32_t)task;
-    dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
-  }
-  if (COMPACT) {
-    // compaction by wavefront ballot: rank within the wave from the ballot mask, one atomic
-    // per wave reserves a contiguous run in the next queue.
-    const unsigned long long mask = __ballot(cont);
-    const unsigned lane = lane_id();
-    const unsigned total = __popcll(mask);
-    unsigned base = 0;
-    if (lane == 0 && total) base = atomicAdd(count_out + p * kCountStride, total);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (cont) {
-      const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
-      const uint32_t j = p * cap + base + rank;
-      next.px[j] = ray.pos.x; next.py[j] = ray.pos.y; next.pz[j] = ray.pos.z;
-      next.dx[j] = ray.dir.x; next.dy[j] = ray.dir.y; next.dz[j] = ray.dir.z;
-      next.cr[j] = col.x; next.cg[j] = col.y; next.cb[j] = col.z;
-      next.pixel[j] = task;
+  for (; first < n_in; first += step) {
+    const uint32_t i = region_base + first + threadIdx.x;
+    const bool in_queue = first + threadIdx.x < n_in;
+    int32_t task = -1;
+    Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
+    f3 col = splat3(0.0f);
+    uint32_t pixel = 0, iter = 0;
+    {
+      const BounceArgs* ka = kernarg_bounce();
+      if (FIRST) {
+        task = in_queue ? (int32_t)i : -1;                            // initially slot == task (raytrace.cu:101)
+      } else if (in_queue) {
+        const PathState cur = load_uniform(&ka->cur);
+        task = cur.pixel[i];                                          // -1 once the path ended (raytrace.cu:119-124)
+        if (task >= 0) {
+          ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]);
+          ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
+          col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
+        }
+      }
+      const bool active0 = task >= 0;
+      uint32_t s = 0;
+      const uint32_t itk = udivmod(active0 ? (uint32_t)task : 0u, load_uniform(&ka->fp.div_tile), s);
+      pixel = load_uniform(&ka->fp.pix0) + s;
+      iter = load_uniform(&ka->iter_first) + itk * load_uniform(&ka->iter_stride);
+      if (FIRST) {
+        const FrameParams cf = load_uniform(&ka->fp);                 // camera and image fields: only here
+        ray = camera_sample(cf, pixel, iter);                         // initBuffersKernel, raytrace.cu:72-96
+        col = splat3(1.0f);                                           // raytrace.cu:99
+        n_paths += active0 ? 1u : 0u;
+      }
     }
-  } else if (active) {
-    if (cont) {
-      cur.px[i] = ray.pos.x; cur.py[i] = ray.pos.y; cur.pz[i] = ray.pos.z;
-      cur.dx[i] = ray.dir.x; cur.dy[i] = ray.dir.y; cur.dz[i] = ray.dir.z;
-      cur.cr[i] = col.x; cur.cg[i] = col.y; cur.cb[i] = col.z;
-      if (FIRST) cur.pixel[i] = task;
-    } else {
-      cur.pixel[i] = -1;                                              // raytrace.cu:132,139
+    const bool active = task >= 0;                                    // raytrace.cu:119-124
+    const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true, true, true)
+                               : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, fp.sc.xf, true, true);
+    const bool cont = (res == STEP_CONTINUE);
+    const BounceArgs* ka = kernarg_bounce();
+    if (res == STEP_LIGHT || res == STEP_BLACK) {
+      // Every path writes its sample when it ends -- the radiance it carried to the light, or the zero that bounce_step()
+      // left in `col` for a miss or the depth cap -- exactly once per slot of the chunk, as k_queue does: the staging
+      // buffer needs no clearing (round 2 zero-filled 0.9 GB per 300 iterations here and wrote only at the light).
+      float* dst = load_uniform(&ka->stage) + 3ull * (uint32_t)task;
+      dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
     }
+    if (COMPACT) {
+      // compaction by wavefront ballot: rank within the wave from the ballot mask, one atomic
+      // per wave reserves a contiguous run in the next queue.
+      const unsigned long long mask = __ballot(cont);
+      const unsigned lane = lane_id();
+      const unsigned total = __popcll(mask);
+      unsigned base = 0;
+      if (lane == 0 && total) base = atomicAdd(load_uniform(&ka->count_out) + p * kCountStride, total);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (cont) {
+        const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+        const uint32_t j = region_base + base + rank;
+        const PathState next = load_uniform(&ka->next);
+        next.px[j] = ray.pos.x; next.py[j] = ray.pos.y; next.pz[j] = ray.pos.z;
+        next.dx[j] = ray.dir.x; next.dy[j] = ray.dir.y; next.dz[j] = ray.dir.z;
+        next.cr[j] = col.x; next.cg[j] = col.y; next.cb[j] = col.z;
+        next.pixel[j] = task;
+      }
+    } else if (active) {
+      const PathState cur = load_uniform(&ka->cur);
+      if (cont) {
+        cur.px[i] = ray.pos.x; cur.py[i] = ray.pos.y; cur.pz[i] = ray.pos.z;
+        cur.dx[i] = ray.dir.x; cur.dy[i] = ray.dir.y; cur.dz[i] = ray.dir.z;
+        cur.cr[i] = col.x; cur.cg[i] = col.y; cur.cb[i] = col.z;
+        if (FIRST) cur.pixel[i] = task;
+      } else {
+        cur.pixel[i] = -1;                                            // raytrace.cu:132,139
+      }
+    }
+    n_live += active ? 1u : 0u;
   }
-  n_live += active ? 1u : 0u;
-  }
+  DeviceCounters* counters = load_uniform(&kernarg_bounce()->counters);
   if (FIRST) count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, (unsigned long long)n_paths);
   count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, (unsigned long long)n_live);
   count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
@@ -1005,7 +1039,10 @@ void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t
     const uint32_t* cin = compact ? queue_count + d * kRegions * kCountStride : nullptr;
     uint32_t* cout = compact ? queue_count + (d + 1) * kRegions * kCountStride : nullptr;
     const PathState out = compact ? next : cur;
-#define TRC_LAUNCH_BOUNCE(C, L, F) hipLaunchKernelGGL((k_bounce<C, L, F>), bgrid, block, 0, stream, fp, iter_first, iter_stride, n_slots, d, bpr, cur, out, cin, cout, stage, counters)
+    BounceArgs ba;
+    ba.fp = fp; ba.iter_first = iter_first; ba.iter_stride = iter_stride; ba.n_slots = n_slots; ba.bpr = bpr; ba.depth = d;
+    ba.cur = cur; ba.next = out; ba.count_in = cin; ba.count_out = cout; ba.stage = stage; ba.counters = counters;
+#define TRC_LAUNCH_BOUNCE(C, L, F) hipLaunchKernelGGL((k_bounce<C, L, F>), bgrid, block, 0, stream, ba)
     if (compact) { if (lds) { if (first) TRC_LAUNCH_BOUNCE(true, true, true); else TRC_LAUNCH_BOUNCE(true, true, false); }
                    else     { if (first) TRC_LAUNCH_BOUNCE(true, false, true); else TRC_LAUNCH_BOUNCE(true, false, false); } }
     else         { if (lds) { if (first) TRC_LAUNCH_BOUNCE(false, true, true); else TRC_LAUNCH_BOUNCE(false, true, false); }
