@@ -82,6 +82,24 @@ __device__ __forceinline__ T load_uniform(const T* p) {
   return out;
 }
 
+// A pointer that was read back from the kernel-argument segment or from a record (load_uniform) has lost its address
+// space, and the compiler falls back to flat_load / flat_store / flat_atomic: instructions that count on BOTH memory
+// counters (vmcnt and lgkmcnt), so that every later wait for an LDS read also waits for them -- and the kernels wait for
+// LDS reads all the time. Every such pointer here points to global memory: say so.
+template <typename T> using gptr = T __attribute__((address_space(1)))*;
+template <typename T> __device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)p; }
+// a record of whole dwords from global memory (per-lane address)
+template <typename T>
+__device__ __forceinline__ T load_global(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword records");
+  const gptr<const unsigned int> q = (gptr<const unsigned int>)p;
+  T out;
+  unsigned int* o = reinterpret_cast<unsigned int*>(&out);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = q[i];
+  return out;
+}
+
 // Where a loop body takes an object's wave-uniform matrix from.
 //   XF_SGPR: scalar loads (s_load_dwordx4/x8 through the constant address space) -> the entries are SGPR operands of the
 //            VALU instructions. No VGPRs, but a v_mul_f32 / v_add_f32 / v_fma_f32 with an SGPR source issues in 4.25 cycles
@@ -271,7 +289,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
     for (uint32_t base = 0; base < count; base += 64u) {
       const uint32_t ti = base + tl;
       const lmask tvalid = lane_used & TRC_UCMP(ti, count, I_ULT);
-      const DevTri tri = tris[first + (lane_of(tvalid) ? ti : 0u)];
+      const DevTri tri = load_global(&tris[first + (lane_of(tvalid) ? ti : 0u)]);
       for (unsigned s0 = 0; s0 < n_pass; s0 += R) {
         TRC_MARK("mesh_pass");
         const unsigned slot = s0 + sub;
@@ -297,7 +315,7 @@ __device__ __forceinline__ float mesh_closest(const Ray& r, lmask mask, const De
   } else if (pass) {
     for (uint32_t i = 0; i < count; ++i) {
       f3 n;
-      float t = hit_triangle(r, tris[first + i], n);
+      float t = hit_triangle(r, load_global(&tris[first + i]), n);
       if (t > 0.0f && t < best) { best = t; bn = n; }
     }
   }
@@ -543,10 +561,10 @@ __device__ __forceinline__ void pairs_pass(Closest& c, const PairFetch& f, const
           // a big mesh whose brute-force pass ran before this kernel (kernels.hip: k_mesh_brute): the winning face
           // is evaluated once more for its normal (same arithmetic, same t)
           if (lane_of(mj)) {
-            const unsigned long long key = sc.mesh_keys[(size_t)ex.big_slot * sc.key_stride + ray_slot];
+            const unsigned long long key = as_global(sc.mesh_keys)[(size_t)ex.big_slot * sc.key_stride + ray_slot];
             if ((uint32_t)(key >> 32) != 0x7f7fffffu) {
               f3 n;
-              const float t = hit_triangle(r, sc.tris[ex.tri_first + (uint32_t)key], n);
+              const float t = hit_triangle(r, load_global(&sc.tris[ex.tri_first + (uint32_t)key]), n);
               if (t > 0.0f) { tb = t; bn = n; }
             }
           }

@@ -117,10 +117,15 @@ __device__ __forceinline__ const FrameParams* kernarg_params() {
 enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE = 3 };
 
 // `fp_is_arg0`: the calling kernel's argument 0 is this FrameParams (see kernarg_params()).
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_trace`: called by every lane once the closest hit is known and before the shading -- the point of a trip where
+// the fewest registers are live (k_bounce issues the loads of its NEXT trip's ray state there, so that they are under
+// way during the shading arithmetic instead of in front of an idle wavefront).
+template <class Hook = NoHook>
 __device__ __forceinline__ int bounce_step(const FrameParams& fp_in, bool live, uint32_t pixel, uint32_t iter, int depth,
                                            Ray& ray, f3& col, uint32_t& tri_tests, uint32_t slot = 0u,
                                            const DevXform* __restrict__ gather = nullptr, bool gather_given = false,
-                                           bool fp_is_arg0 = false, bool xf_in_lds = false) {
+                                           bool fp_is_arg0 = false, bool xf_in_lds = false, Hook after_trace = Hook()) {
   DevScene sc_again;
   if (fp_is_arg0) sc_again = load_uniform(&kernarg_params()->sc);
   const DevScene& sc = fp_is_arg0 ? sc_again : fp_in.sc;
@@ -129,12 +134,13 @@ __device__ __forceinline__ int bounce_step(const FrameParams& fp_in, bool live, 
 #endif
   Hit hit = (TRC_XF_LDS && xf_in_lds) ? closest_hit<XF_LDS>(ray, live, sc, tri_tests, slot, gather)
                                       : closest_hit<XF_SGPR>(ray, live, sc, tri_tests, slot, gather_given ? gather : sc.xf);
+  after_trace();
   if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
   FrameParams again;
   if (fp_is_arg0) again = load_uniform(kernarg_params());
   const FrameParams& fp = fp_is_arg0 ? again : fp_in;
-  const DevMaterial& o = fp.sc.mats[hit.id];
+  const DevMaterial o = load_global(&fp.sc.mats[hit.id]);
   const f3 mcolor = o.color;
   const float emit = o.emit;
   if (emit > 0.0f) { col = col * (mcolor * emit); return STEP_LIGHT; }      // :137-141
@@ -619,6 +625,23 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
   const uint32_t step = bpr * kBlock;
   const int depth = a.depth;
   uint32_t tt = 0, n_live = 0, n_paths = 0;
+  // A trip's ray state as it sits in memory. The loads of trip n + 1 are issued in the middle of trip n (bounce_step's
+  // after_trace hook: after the closest hit, ~400 instructions ahead of their use) instead of in front of an idle wavefront.
+  struct State { int32_t task; float px, py, pz, dx, dy, dz, cr, cg, cb; };
+  auto load_state = [&](uint32_t f) -> State {
+    State L; L.task = -1; L.px = L.py = L.pz = L.dx = L.dy = L.dz = L.cr = L.cg = L.cb = 0.0f;
+    if (FIRST || f >= n_in) return L;                                 // (wave-uniform)
+    const PathState cur = load_uniform(&kernarg_bounce()->cur);
+    if (f + threadIdx.x < n_in) {
+      const uint32_t j = region_base + f + threadIdx.x;
+      L.task = as_global(cur.pixel)[j];                               // -1 once the path ended (raytrace.cu:119-124)
+      L.px = as_global(cur.px)[j]; L.py = as_global(cur.py)[j]; L.pz = as_global(cur.pz)[j];
+      L.dx = as_global(cur.dx)[j]; L.dy = as_global(cur.dy)[j]; L.dz = as_global(cur.dz)[j];
+      L.cr = as_global(cur.cr)[j]; L.cg = as_global(cur.cg)[j]; L.cb = as_global(cur.cb)[j];
+    }
+    return L;
+  };
+  State st = load_state(first);
   for (; first < n_in; first += step) {
     const uint32_t i = region_base + first + threadIdx.x;
     const bool in_queue = first + threadIdx.x < n_in;
@@ -630,14 +653,11 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
       const BounceArgs* ka = kernarg_bounce();
       if (FIRST) {
         task = in_queue ? (int32_t)i : -1;                            // initially slot == task (raytrace.cu:101)
-      } else if (in_queue) {
-        const PathState cur = load_uniform(&ka->cur);
-        task = cur.pixel[i];                                          // -1 once the path ended (raytrace.cu:119-124)
-        if (task >= 0) {
-          ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]);
-          ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]);
-          col = mk3(cur.cr[i], cur.cg[i], cur.cb[i]);
-        }
+      } else {
+        task = st.task;
+        ray.pos = mk3(st.px, st.py, st.pz);
+        ray.dir = mk3(st.dx, st.dy, st.dz);
+        col = mk3(st.cr, st.cg, st.cb);
       }
       const bool active0 = task >= 0;
       uint32_t s = 0;
@@ -651,16 +671,18 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
         n_paths += active0 ? 1u : 0u;
       }
     }
+    const uint32_t first_next = first + step;
+    auto prefetch = [&]() { if (!FIRST) st = load_state(first_next); };          // (past the queue's end: an empty state, no loads)
     const bool active = task >= 0;                                    // raytrace.cu:119-124
-    const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true, true, true)
-                               : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, fp.sc.xf, true, true);
+    const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true, true, true, prefetch)
+                               : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, fp.sc.xf, true, true, false, prefetch);
     const bool cont = (res == STEP_CONTINUE);
     const BounceArgs* ka = kernarg_bounce();
     if (res == STEP_LIGHT || res == STEP_BLACK) {
       // Every path writes its sample when it ends -- the radiance it carried to the light, or the zero that bounce_step()
       // left in `col` for a miss or the depth cap -- exactly once per slot of the chunk, as k_queue does: the staging
       // buffer needs no clearing (round 2 zero-filled 0.9 GB per 300 iterations here and wrote only at the light).
-      float* dst = load_uniform(&ka->stage) + 3ull * (uint32_t)task;
+      gptr<float> dst = as_global(load_uniform(&ka->stage)) + 3ull * (uint32_t)task;
       dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
     }
     if (COMPACT) {
@@ -670,26 +692,27 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
       const unsigned lane = lane_id();
       const unsigned total = __popcll(mask);
       unsigned base = 0;
-      if (lane == 0 && total) base = atomicAdd(load_uniform(&ka->count_out) + p * kCountStride, total);
+      if (lane == 0 && total) base = __hip_atomic_fetch_add(as_global(load_uniform(&ka->count_out)) + p * kCountStride, total,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       base = __builtin_amdgcn_readfirstlane(base);
       if (cont) {
         const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
         const uint32_t j = region_base + base + rank;
         const PathState next = load_uniform(&ka->next);
-        next.px[j] = ray.pos.x; next.py[j] = ray.pos.y; next.pz[j] = ray.pos.z;
-        next.dx[j] = ray.dir.x; next.dy[j] = ray.dir.y; next.dz[j] = ray.dir.z;
-        next.cr[j] = col.x; next.cg[j] = col.y; next.cb[j] = col.z;
-        next.pixel[j] = task;
+        as_global(next.px)[j] = ray.pos.x; as_global(next.py)[j] = ray.pos.y; as_global(next.pz)[j] = ray.pos.z;
+        as_global(next.dx)[j] = ray.dir.x; as_global(next.dy)[j] = ray.dir.y; as_global(next.dz)[j] = ray.dir.z;
+        as_global(next.cr)[j] = col.x; as_global(next.cg)[j] = col.y; as_global(next.cb)[j] = col.z;
+        as_global(next.pixel)[j] = task;
       }
     } else if (active) {
       const PathState cur = load_uniform(&ka->cur);
       if (cont) {
-        cur.px[i] = ray.pos.x; cur.py[i] = ray.pos.y; cur.pz[i] = ray.pos.z;
-        cur.dx[i] = ray.dir.x; cur.dy[i] = ray.dir.y; cur.dz[i] = ray.dir.z;
-        cur.cr[i] = col.x; cur.cg[i] = col.y; cur.cb[i] = col.z;
-        if (FIRST) cur.pixel[i] = task;
+        as_global(cur.px)[i] = ray.pos.x; as_global(cur.py)[i] = ray.pos.y; as_global(cur.pz)[i] = ray.pos.z;
+        as_global(cur.dx)[i] = ray.dir.x; as_global(cur.dy)[i] = ray.dir.y; as_global(cur.dz)[i] = ray.dir.z;
+        as_global(cur.cr)[i] = col.x; as_global(cur.cg)[i] = col.y; as_global(cur.cb)[i] = col.z;
+        if (FIRST) as_global(cur.pixel)[i] = task;
       } else {
-        cur.pixel[i] = -1;                                            // raytrace.cu:132,139
+        as_global(cur.pixel)[i] = -1;                                 // raytrace.cu:132,139
       }
     }
     n_live += active ? 1u : 0u;
@@ -831,7 +854,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
         if (__builtin_expect(pool_next == pool_end, 0)) {
           const uint32_t grab = load_uniform(&ka->grab), total = load_uniform(&ka->total);
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(load_uniform(&ka->next_task), grab);
+          if (lane == 0) base = __hip_atomic_fetch_add(as_global(load_uniform(&ka->next_task)), grab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
           if (base >= total) { exhausted = true; break; }
           pool_next = base;
@@ -885,7 +908,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
       // bounce_step() left in `col` for a miss or the depth cap -- so the staging buffer needs no clearing
       // (some lane of a wavefront reaches the light on nine trips out of ten: the stores were issued anyway).
       const QueueArgs* ka = kernarg_queue();
-      float* dst = load_uniform(&ka->stage) + 3ull * ((unsigned long long)itk * load_uniform(&ka->fp.ntile) + (pixel - load_uniform(&ka->fp.pix0)));
+      gptr<float> dst = as_global(load_uniform(&ka->stage)) + 3ull * ((unsigned long long)itk * load_uniform(&ka->fp.ntile) + (pixel - load_uniform(&ka->fp.pix0)));
       dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
       have = false;
     }
