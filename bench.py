@@ -16,7 +16,10 @@ followed by the display transform on rank 0 -- the only exchange the path has
 
 Rank 0 prints one JSON line. Beside the contract's fields it carries
   roofline        the dominant kernel (k_queue) against the FP32 vector peak and against the measured VALU issue ceiling
-  cpu_baseline    the CPU oracle on the host cores (bounded sample)                              [N == 1]
+  film_check      N == 1: sha1 of the film and LDR image the timed steps left behind against the value recorded from the
+                  reference host build (tests/golden/meta.json); N > 1: the reduced film against the one-rank film
+  cpu_baseline    the reference host build (oracle/_ref) on the host cores, one process per core (bounded sample) [N == 1]
+  multi_gpu       N > 1: duration of the film sum-reduce, the one-GPU rate on the same workload, efficiency_vs_n1
   extra_configs   short runs of BASELINE.json configs[2], [3], [4] and of the compacted pipeline [N == 1]
   config4_strong  configs[3]'s shape, 3840x2160, a fixed number of samples split over the N GPUs (strong scaling)
 Only the `cpu_baseline` leg touches oracle/.
@@ -238,7 +241,7 @@ def timed_render(tr, cam, seed, iters, reps, pipeline=None):
     return min(ms), statistics.median(ms), cnt
 
 
-def extra_configs(ta):
+def extra_configs(ta, k_queue_ms=None):
     """Short runs of the other BASELINE.json configurations on one GPU (rank 0, N == 1). Rates are per call, from HIP
     events on the launch stream; rooflines use the nominal algorithmic costs of SURVEY.md 8(d)."""
     out = []
@@ -271,7 +274,14 @@ def extra_configs(ta):
     if t_bytes:
         gbs = t_bytes / (e["kernel_ms_min"] * 1e-3) / 1e9
         e["hbm"] = {"traffic": t_bytes, "traffic_source": src, "achieved_GBs": round(gbs, 1), "peak_GBs": PEAK_HBM_GBS,
-                    "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
+                    "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "algorithmic_bytes": int(e["live_segments"] * 80 + 12 * W * H * ITERS * 2),
+                    "algorithmic_note": "40 B of ray state read and 40 B written per live segment (the reference's per-bounce buffers, "
+                                        "raytrace.cu:107-160) + 12 B per path staged and read back once"}
+        if k_queue_ms:
+            # the same closest-hit arithmetic bounds this pipeline as it bounds k_queue: its HBM rate cannot exceed the
+            # traffic over the time the arithmetic alone takes (the work-queue pipeline's kernel time, which moves no ray state)
+            e["hbm"]["hbm_frac_ceiling_set_by_the_valu"] = round(t_bytes / (k_queue_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
     out.append(e)
 
     # configs[0]'s kernel (mode 1: one closest hit + flat shade per pixel, raytrace.cu:29-62) at 3840x2160, and the same
@@ -534,7 +544,7 @@ def main():
         paths_per_launch = cnt["paths"] / args.steps
         flop = seg_per_launch * FLOP_PER_SEGMENT + paths_per_launch * FLOP_PER_PATH
         achieved = flop / (k_ms * 1e-3) / 1e12
-        kernel_name = {0: "k_bounce<false> (+k_raygen)", 1: "k_bounce<true> (+k_raygen, k_accumulate)", 2: "k_fused",
+        kernel_name = {0: "k_bounce<false> (+k_accumulate)", 1: "k_bounce<true> (+k_accumulate)", 2: "k_fused",
                        3: "k_queue (+k_accumulate)", 4: "k_queue (+k_accumulate)"}[args.pipeline]
         out = {
             "metric": "Mpath-segments/s, Cornell box 512x512 path trace (mode 2), 300 iterations",
@@ -620,7 +630,7 @@ def main():
             out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
         tr.close()
         if world == 1 and not args.no_extra:
-            out["extra_configs"] = extra_configs(ta)
+            out["extra_configs"] = extra_configs(ta, k_ms)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
