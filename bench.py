@@ -333,7 +333,10 @@ def extra_configs(ta, k_queue_ms=None):
                            "flop_per_pair": round(fpp, 3), "flop_per_pair_source": rates["_file"],
                            "exit_rates_Ray.inl_196_203_208_none": [round(rates["exit_rates"][k], 8) for k in ("det", "bary_x", "bary_y", "full")],
                            "note": "reference flop per pair = exit-stage costs 20/30/46/74 (SURVEY.md 8d) weighted by where Ray.inl:189-226 "
-                                   "leaves on this frame; the frame time also holds k_mesh_rays and k_raytrace1 (< 1 %)"})
+                                   "leaves on this frame; the frame time also holds k_mesh_rays and k_raytrace1 (< 1 %). This is the "
+                                   "REFERENCE's arithmetic per unit of time, not what the kernel issues: with mesh_accel 0 nearly every pair "
+                                   "is decided by a 10-instruction conservative bounding-sphere test (same hits, bit for bit), so the figure "
+                                   "says how fast the reference's work gets done; how busy the VALU is says valu_issue_utilisation"})
             p = (prof or {}).get("by_mesh_accel", {}).get(str(accel))
             mhz = cnt.get("shader_mhz")
             if p:
