@@ -34,14 +34,18 @@ inline void set_dims(FrameParams& fp, uint32_t w, uint32_t h) {
   fp.fw = (float)w; fp.fh = (float)h; fp.rcp_w = 1.0f / fp.fw; fp.rcp_h = 1.0f / fp.fh;
 }
 
-// Per-path state of the wavefront pipelines, planar (one float per lane per plane, so every
-// load/store instruction of a wavefront covers 256 contiguous bytes). Two of these are
-// ping-ponged by the compacting pipeline.
+// Per-path state of the wavefront pipelines: 40 bytes per path in three planar arrays of 16-, 16- and 8-byte elements,
+// so that a wavefront moves a path's state with three load and three store instructions, each covering 1 KB / 512 B of
+// contiguous memory (round 2 kept ten planar dword arrays: ten instructions each way, and after compaction a wavefront's
+// run of survivors starts anywhere, so each of them touched two or three partly written cache lines -- the stores alone
+// cost a fifth of a bounce launch). Two of these are ping-ponged by the compacting pipeline.
+//   a[i] = (pos.x, pos.y, pos.z, dir.x)    b[i] = (dir.y, dir.z, col.r, col.g)    c[i] = (col.b, bits of the task number)
+// task = the path's slot in the sample staging (iteration-in-chunk * tile pixels + pixel); -1 once the path has ended
+// (raytrace.cu:119-124: idx_d).
 struct PathState {
-  float* px; float* py; float* pz;     // ray origin      (Ray::m_pos)
-  float* dx; float* dy; float* dz;     // ray direction   (Ray::m_dir)
-  float* cr; float* cg; float* cb;     // throughput      (col_d)
-  int32_t* pixel;                      // owning pixel, or -1 once terminated (idx_d)
+  float4* a;
+  float4* b;
+  float2* c;
 };
 
 // Event counters, banked: a workgroup adds to bank blockIdx.x % kCounterBanks, each bank in a 256-byte

@@ -30,6 +30,14 @@ __host__ __device__ inline uint32_t gather_records(const DevScene& sc) { return 
 
 static inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
+// 16- and 8-byte elements of the per-path state (kernels.h: PathState) through global-address-space pointers
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f ldg4(const float4* p, size_t j) { return ((gptr<const v4f>)p)[j]; }
+__device__ __forceinline__ v2f ldg2(const float2* p, size_t j) { return ((gptr<const v2f>)p)[j]; }
+__device__ __forceinline__ void stg4(float4* p, size_t j, float x, float y, float z, float w) { v4f v = { x, y, z, w }; ((gptr<v4f>)p)[j] = v; }
+__device__ __forceinline__ void stg2(float2* p, size_t j, float x, float y) { v2f v = { x, y }; ((gptr<v2f>)p)[j] = v; }
+
 // Wavefront pipelines: the path slots of a launch sequence are split into kRegions contiguous regions of
 // `cap` slots (a multiple of the workgroup size). A workgroup belongs to one region; survivors of a bounce
 // are compacted WITHIN their region (they can only become fewer), with one live count per region and
@@ -272,8 +280,11 @@ __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t m
   } else if (SOURCE == 2) {
     if (live) { const float* r = rays6 + 6ull * i; ray.pos = mk3(r[0], r[1], r[2]); ray.dir = mk3(r[3], r[4], r[5]); }
   } else {
-    live = live && cur.pixel[i] >= 0;
-    if (live) { ray.pos = mk3(cur.px[i], cur.py[i], cur.pz[i]); ray.dir = mk3(cur.dx[i], cur.dy[i], cur.dz[i]); }
+    if (live) {
+      const float4 A = cur.a[i], B = cur.b[i];
+      live = __float_as_int(cur.c[i].y) >= 0;
+      if (live) { ray.pos = mk3(A.x, A.y, A.z); ray.dir = mk3(A.w, B.x, B.y); }
+    }
   }
   const DevXform& xf = fp.sc.xf[fp.sc.n_plane + fp.sc.n_sphere + fp.sc.n_cube + mesh_index];
   const DevMeshExtra& ex = fp.sc.meshes[mesh_index];
@@ -567,10 +578,9 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
     uint32_t s;
     const uint32_t itk = udivmod(idx, fp.div_tile, s);
     Ray ray = camera_sample(fp, fp.pix0 + s, iter_first + itk * iter_stride);
-    st.px[idx] = ray.pos.x; st.py[idx] = ray.pos.y; st.pz[idx] = ray.pos.z;
-    st.dx[idx] = ray.dir.x; st.dy[idx] = ray.dir.y; st.dz[idx] = ray.dir.z;
-    st.cr[idx] = 1.0f; st.cg[idx] = 1.0f; st.cb[idx] = 1.0f;           // raytrace.cu:99
-    st.pixel[idx] = (int32_t)idx;                                     // :101
+    st.a[idx] = make_float4(ray.pos.x, ray.pos.y, ray.pos.z, ray.dir.x);
+    st.b[idx] = make_float4(ray.dir.y, ray.dir.z, 1.0f, 1.0f);          // throughput (1, 1, 1): raytrace.cu:99
+    st.c[idx] = make_float2(1.0f, __int_as_float((int32_t)idx));        // :101
   }
   count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, valid ? 1ull : 0ull);
 }
@@ -634,10 +644,10 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
     const PathState cur = load_uniform(&kernarg_bounce()->cur);
     if (f + threadIdx.x < n_in) {
       const uint32_t j = region_base + f + threadIdx.x;
-      L.task = as_global(cur.pixel)[j];                               // -1 once the path ended (raytrace.cu:119-124)
-      L.px = as_global(cur.px)[j]; L.py = as_global(cur.py)[j]; L.pz = as_global(cur.pz)[j];
-      L.dx = as_global(cur.dx)[j]; L.dy = as_global(cur.dy)[j]; L.dz = as_global(cur.dz)[j];
-      L.cr = as_global(cur.cr)[j]; L.cg = as_global(cur.cg)[j]; L.cb = as_global(cur.cb)[j];
+      const v4f A = ldg4(cur.a, j), B = ldg4(cur.b, j);
+      const v2f Cc = ldg2(cur.c, j);
+      L.task = __float_as_int(Cc.y);                                  // -1 once the path ended (raytrace.cu:119-124)
+      L.px = A.x; L.py = A.y; L.pz = A.z; L.dx = A.w; L.dy = B.x; L.dz = B.y; L.cr = B.z; L.cg = B.w; L.cb = Cc.x;
     }
     return L;
   };
@@ -699,20 +709,18 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
         const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
         const uint32_t j = region_base + base + rank;
         const PathState next = load_uniform(&ka->next);
-        as_global(next.px)[j] = ray.pos.x; as_global(next.py)[j] = ray.pos.y; as_global(next.pz)[j] = ray.pos.z;
-        as_global(next.dx)[j] = ray.dir.x; as_global(next.dy)[j] = ray.dir.y; as_global(next.dz)[j] = ray.dir.z;
-        as_global(next.cr)[j] = col.x; as_global(next.cg)[j] = col.y; as_global(next.cb)[j] = col.z;
-        as_global(next.pixel)[j] = task;
+        stg4(next.a, j, ray.pos.x, ray.pos.y, ray.pos.z, ray.dir.x);
+        stg4(next.b, j, ray.dir.y, ray.dir.z, col.x, col.y);
+        stg2(next.c, j, col.z, __int_as_float(task));
       }
     } else if (active) {
       const PathState cur = load_uniform(&ka->cur);
       if (cont) {
-        as_global(cur.px)[i] = ray.pos.x; as_global(cur.py)[i] = ray.pos.y; as_global(cur.pz)[i] = ray.pos.z;
-        as_global(cur.dx)[i] = ray.dir.x; as_global(cur.dy)[i] = ray.dir.y; as_global(cur.dz)[i] = ray.dir.z;
-        as_global(cur.cr)[i] = col.x; as_global(cur.cg)[i] = col.y; as_global(cur.cb)[i] = col.z;
-        if (FIRST) as_global(cur.pixel)[i] = task;
+        stg4(cur.a, i, ray.pos.x, ray.pos.y, ray.pos.z, ray.dir.x);
+        stg4(cur.b, i, ray.dir.y, ray.dir.z, col.x, col.y);
+        stg2(cur.c, i, col.z, __int_as_float(task));
       } else {
-        as_global(cur.pixel)[i] = -1;                                 // raytrace.cu:132,139
+        stg2(cur.c, i, 0.0f, __int_as_float(-1));                     // raytrace.cu:132,139
       }
     }
     n_live += active ? 1u : 0u;

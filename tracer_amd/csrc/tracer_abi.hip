@@ -177,10 +177,7 @@ int ensure_wavefront_state(trc_ctx* c, bool need_second, size_t slots) {
     HIP_TRY(hipMalloc((void**)&c->state_mem[b], sizeof(float) * 10ull * n));
     float* p = c->state_mem[b];
     PathState& s = c->state[b];
-    s.px = p; s.py = p + n; s.pz = p + 2ull * n;
-    s.dx = p + 3ull * n; s.dy = p + 4ull * n; s.dz = p + 5ull * n;
-    s.cr = p + 6ull * n; s.cg = p + 7ull * n; s.cb = p + 8ull * n;
-    s.pixel = (int32_t*)(p + 9ull * n);
+    s.a = (float4*)p; s.b = (float4*)(p + 4ull * n); s.c = (float2*)(p + 8ull * n);      // 16 + 16 + 8 bytes per slot
   }
   if (!c->queue_count) HIP_TRY(hipMalloc((void**)&c->queue_count, sizeof(uint32_t) * (kPathDepth + 1) * kRegions * kCountStride));
   return TRC_OK;
