@@ -42,7 +42,7 @@ def test_multi_gpu_library_exports_every_declared_symbol(product_lib):
     out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
     exported = set(line.split()[-1] for line in out.splitlines() if " T " in line)
     declared = [s for s in declared_symbols("tracer_multi.h") if s.startswith("trc_multi_")]
-    assert len(declared) == 12, declared
+    assert len(declared) == 13, declared
     assert not [s for s in declared if s not in exported]
     needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True, check=True).stdout
     assert "librccl" in needed and "libtracer_amd.so" in needed
