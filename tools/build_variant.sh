@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../tracer_amd/csrc"
 name=$1; shift
 mkdir -p ../variants /tmp/trcvar_$name
-F="--offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -Wno-unused-function -Wno-unknown-pragmas $*"
+F="--offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -Wno-unused-function -Wno-unknown-pragmas $*"
 /opt/rocm/bin/hipcc $F -c kernels.hip -o /tmp/trcvar_$name/kernels.o &
 /opt/rocm/bin/hipcc $F -c tracer_abi.hip -o /tmp/trcvar_$name/tracer_abi.o &
 wait

@@ -66,7 +66,7 @@ struct DeviceCounters { CounterBank bank[kCounterBanks]; };
 // region p entering bounce d is queue_count[(d * kRegions + p) * kCountStride] (256 bytes apart).
 constexpr uint32_t kRegions = 256;
 constexpr uint32_t kCountStride = 64;
-constexpr uint32_t kRegionSlack = kRegions * 256;   // slots beyond ntile * n_iters that the region layout may address
+constexpr uint32_t kRegionSlack = kRegions * 512;   // slots beyond ntile * n_iters that the region layout may address
 
 // ---- big meshes (scene.h: kBigMeshTris): brute-force pass in front of a closest-hit kernel ------
 struct BigMesh {                    // host-side list, in big_slot order

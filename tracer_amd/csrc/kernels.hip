@@ -45,7 +45,10 @@ __device__ __forceinline__ void stg2(float2* p, size_t j, float x, float y) { v2
 // launch go to 256 addresses instead of one (same measurement as for the counters, kernels.h).
 __host__ __device__ inline uint32_t region_cap(uint32_t n_slots) {
   const uint32_t per = (n_slots + kRegions - 1) / kRegions;
-  const uint32_t cap = (per + kBlock - 1) / kBlock * kBlock;
+  // an ODD number of 256-slot blocks: the regions advance side by side, and with a region stride of 2^16 x 75 bytes (the
+  // headline workload) the 256 wavefronts that work at the same offset of their regions met in the same memory channels
+  // (compacted pipeline 8.56 -> 8.36 ms)
+  const uint32_t cap = (((per + kBlock - 1) / kBlock) | 1u) * kBlock;
   return cap ? cap : (uint32_t)kBlock;
 }
 __device__ __forceinline__ uint32_t region_initial(uint32_t n_slots, uint32_t cap, uint32_t p) {
@@ -125,15 +128,19 @@ __device__ __forceinline__ const FrameParams* kernarg_params() {
 enum StepResult { STEP_CONTINUE = 0, STEP_BLACK = 1, STEP_LIGHT = 2, STEP_IDLE = 3 };
 
 // `fp_is_arg0`: the calling kernel's argument 0 is this FrameParams (see kernarg_params()).
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// `after_trace`: called by every lane once the closest hit is known and before the shading -- the point of a trip where
-// the fewest registers are live (k_bounce issues the loads of its NEXT trip's ray state there, so that they are under
-// way during the shading arithmetic instead of in front of an idle wavefront).
+struct NoHook { __device__ __forceinline__ void operator()(bool) const {} };
+// `decided(cont)`: called by every lane (wave-convergent) as soon as the outcome of the trip is known -- the closest hit is
+// found and its material read, `cont` says whether this lane's path goes on -- and before the shading arithmetic: the point
+// of a trip where the fewest registers are live. k_bounce reserves the survivors' run in the next queue and issues the loads
+// of its NEXT trip's ray state there, so that both are under way during the ~300 instructions of the bounce instead of in
+// front of an idle wavefront.
+// `lds_mats`: the kernel's LDS copy of the material table (indexed like sc.mats) where `mats_in_lds`.
 template <class Hook = NoHook>
 __device__ __forceinline__ int bounce_step(const FrameParams& fp_in, bool live, uint32_t pixel, uint32_t iter, int depth,
                                            Ray& ray, f3& col, uint32_t& tri_tests, uint32_t slot = 0u,
                                            const DevXform* __restrict__ gather = nullptr, bool gather_given = false,
-                                           bool fp_is_arg0 = false, bool xf_in_lds = false, Hook after_trace = Hook()) {
+                                           bool fp_is_arg0 = false, bool xf_in_lds = false, Hook decided = Hook(),
+                                           const DevMaterial* lds_mats = nullptr, bool mats_in_lds = false) {
   DevScene sc_again;
   if (fp_is_arg0) sc_again = load_uniform(&kernarg_params()->sc);
   const DevScene& sc = fp_is_arg0 ? sc_again : fp_in.sc;
@@ -142,13 +149,17 @@ __device__ __forceinline__ int bounce_step(const FrameParams& fp_in, bool live, 
 #endif
   Hit hit = (TRC_XF_LDS && xf_in_lds) ? closest_hit<XF_LDS>(ray, live, sc, tri_tests, slot, gather)
                                       : closest_hit<XF_SGPR>(ray, live, sc, tri_tests, slot, gather_given ? gather : sc.xf);
-  after_trace();
+  const bool has_hit = live && hit.id >= 0;
+  DevMaterial o;
+  o.color = splat3(0.0f); o.emit = 0.0f; o.brdf = 0.0f; o.ior = 0.0f; o.mat_type = 0; o.inv_ior = 0.0f;
+  if (mats_in_lds) o = lds_mats[has_hit ? hit.id : 0];
+  else if (has_hit) o = load_global(&sc.mats[hit.id]);
+  decided(has_hit && !(o.emit > 0.0f) && depth != kPathDepth - 1);
   if (!live) return STEP_IDLE;
   if (hit.id < 0) { col = splat3(0.0f); return STEP_BLACK; }               // :130-134
   FrameParams again;
   if (fp_is_arg0) again = load_uniform(kernarg_params());
   const FrameParams& fp = fp_is_arg0 ? again : fp_in;
-  const DevMaterial o = load_global(&fp.sc.mats[hit.id]);
   const f3 mcolor = o.color;
   const float emit = o.emit;
   if (emit > 0.0f) { col = col * (mcolor * emit); return STEP_LIGHT; }      // :137-141
@@ -626,9 +637,12 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
   uint32_t first = (blockIdx.x - p * bpr) * kBlock;
   if (first >= n_in) return;                                          // whole block past its region's queue
   __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];              // as in k_queue: table of the held candidates' gathers
+  __shared__ DevMaterial s_mat[kGatherMax ? kGatherMax : 1];          // and the materials (indexed by original object index)
   if (LDS_GATHER) {
     const uint32_t n_dw = gather_records(fp.sc) * (uint32_t)(sizeof(DevXform) / 4);
     for (uint32_t k = threadIdx.x; k < n_dw; k += kBlock) ((uint32_t*)s_xf)[k] = ((const uint32_t*)fp.sc.xf)[k];
+    const uint32_t m_dw = gather_records(fp.sc) * (uint32_t)(sizeof(DevMaterial) / 4);
+    for (uint32_t k = threadIdx.x; k < m_dw; k += kBlock) ((uint32_t*)s_mat)[k] = ((const uint32_t*)fp.sc.mats)[k];
     __syncthreads();
   }
   const uint32_t region_base = p * cap;
@@ -636,7 +650,7 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
   const int depth = a.depth;
   uint32_t tt = 0, n_live = 0, n_paths = 0;
   // A trip's ray state as it sits in memory. The loads of trip n + 1 are issued in the middle of trip n (bounce_step's
-  // after_trace hook: after the closest hit, ~400 instructions ahead of their use) instead of in front of an idle wavefront.
+  // `decided` hook: ~300 instructions ahead of their use) instead of in front of an idle wavefront.
   struct State { int32_t task; float px, py, pz, dx, dy, dz, cr, cg, cb; };
   auto load_state = [&](uint32_t f) -> State {
     State L; L.task = -1; L.px = L.py = L.pz = L.dx = L.dy = L.dz = L.cr = L.cg = L.cb = 0.0f;
@@ -682,11 +696,29 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
       }
     }
     const uint32_t first_next = first + step;
-    auto prefetch = [&]() { if (!FIRST) st = load_state(first_next); };          // (past the queue's end: an empty state, no loads)
+    // Once the outcome of the trip is known (bounce_step: `decided`): compaction by wavefront ballot -- rank within the
+    // wave from the ballot mask, one atomic per wave reserves a contiguous run in the next queue -- and the loads of the
+    // next trip's state (past the queue's end: an empty state, no loads). The vector-memory counter is in order, so the
+    // ONE wait of a trip (for the atomic's answer, after the shading) covers the loads too, and every store of the trip
+    // is issued after it: nothing waits for a store.
+    const unsigned lane = lane_id();
+    unsigned long long mask = 0ull;
+    unsigned base_v = 0;
+    auto decided = [&](bool cont_) {
+      if (COMPACT) {
+        mask = __ballot(cont_);
+        const unsigned total = __popcll(mask);
+        if (lane == 0 && total) base_v = __hip_atomic_fetch_add(as_global(load_uniform(&kernarg_bounce()->count_out)) + p * kCountStride, total,
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!FIRST) st = load_state(first_next);
+    };
     const bool active = task >= 0;                                    // raytrace.cu:119-124
-    const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true, true, true, prefetch)
-                               : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, fp.sc.xf, true, true, false, prefetch);
+    const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true, true, true, decided, s_mat, true)
+                               : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, fp.sc.xf, true, true, false, decided);
     const bool cont = (res == STEP_CONTINUE);
+    const unsigned base = __builtin_amdgcn_readfirstlane(base_v);     // (waits for the atomic, and with it for the loads)
+    if (!FIRST && !COMPACT) asm volatile("" :: "v"(st.pz), "v"(st.cg), "v"(st.task));   // the same wait where there is no atomic
     const BounceArgs* ka = kernarg_bounce();
     if (res == STEP_LIGHT || res == STEP_BLACK) {
       // Every path writes its sample when it ends -- the radiance it carried to the light, or the zero that bounce_step()
@@ -696,15 +728,6 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
       dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
     }
     if (COMPACT) {
-      // compaction by wavefront ballot: rank within the wave from the ballot mask, one atomic
-      // per wave reserves a contiguous run in the next queue.
-      const unsigned long long mask = __ballot(cont);
-      const unsigned lane = lane_id();
-      const unsigned total = __popcll(mask);
-      unsigned base = 0;
-      if (lane == 0 && total) base = __hip_atomic_fetch_add(as_global(load_uniform(&ka->count_out)) + p * kCountStride, total,
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      base = __builtin_amdgcn_readfirstlane(base);
       if (cont) {
         const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
         const uint32_t j = region_base + base + rank;
@@ -827,10 +850,13 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
   RaySlot* __restrict__ ring = s_ring + (threadIdx.x >> 6) * kRing;
   // The plane / sphere records that held candidates gather per lane (intersect.h: flush_held), copied to LDS once.
   __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];
+  __shared__ DevMaterial s_mat[kGatherMax ? kGatherMax : 1];          // and the materials (indexed by original object index)
   const uint32_t n_gather = gather_records(fp.sc);
   if (LDS_GATHER) {
     const uint32_t n_dw = n_gather * (uint32_t)(sizeof(DevXform) / 4);
     for (uint32_t i = threadIdx.x; i < n_dw; i += kBlock) ((uint32_t*)s_xf)[i] = ((const uint32_t*)fp.sc.xf)[i];
+    const uint32_t m_dw = n_gather * (uint32_t)(sizeof(DevMaterial) / 4);
+    for (uint32_t i = threadIdx.x; i < m_dw; i += kBlock) ((uint32_t*)s_mat)[i] = ((const uint32_t*)fp.sc.mats)[i];
     __syncthreads();
   }
 #ifdef TRC_LDS_PAD          // occupancy experiments: extra LDS so that fewer workgroups fit a CU
@@ -905,7 +931,7 @@ __global__ __launch_bounds__(kBlock, TRC_QUEUE_WAVES) void k_queue(QueueArgs qa)
       ring_count -= taken;
     }
     if (__ballot(have) == 0ull) break;
-    const int res = LDS_GATHER ? bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, s_xf, true, true, true)
+    const int res = LDS_GATHER ? bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, s_xf, true, true, true, NoHook(), s_mat, true)
                                : bounce_step(fp, have, pixel, iter, depth, ray, col, tt, 0u, fp.sc.xf, true, true);
     TRC_MARK("bounce_done");
     if (res == STEP_CONTINUE) {
