@@ -64,9 +64,43 @@ struct DeviceCounters { CounterBank bank[kCounterBanks]; };
 
 // Wavefront pipelines (kernels.hip: region_cap): path slots are split into kRegions regions; the live count of
 // region p entering bounce d is queue_count[(d * kRegions + p) * kCountStride] (256 bytes apart).
-constexpr uint32_t kRegions = 256;
+#ifndef TRC_REGIONS
+#define TRC_REGIONS 256
+#endif
+constexpr uint32_t kRegions = TRC_REGIONS;
 constexpr uint32_t kCountStride = 64;
-constexpr uint32_t kRegionSlack = kRegions * 512;   // slots beyond ntile * n_iters that the region layout may address
+// ... followed by the tile counters of k_bounce's wavefronts, grab[(d * kRegions + p) * kCountStride] for bounce d
+constexpr uint32_t kLiveCountWords = (kPathDepth + 1) * kRegions * kCountStride;
+constexpr uint32_t kQueueCountWords = 2 * kLiveCountWords;
+// Layout of the path slots of a launch sequence: region p owns the slots [p * cap, (p + 1) * cap); it starts with `fill`
+// paths (tasks p * fill ...), and the rest of `cap` is head room for the compacting bounce, whose wavefronts reserve their
+// place in the next queue kBounceBatch slots at a time and leave what they did not use as dead slots (at most 3 batches per
+// wavefront). `cap` is an ODD number of 256-slot blocks: the regions advance side by side, and with a power of two in the
+// region stride the 256 wavefronts that work at the same offset of their regions met in the same memory channels.
+#ifndef TRC_BOUNCE_BPR
+#define TRC_BOUNCE_BPR 5           // k_bounce: workgroups per region (kernels.hip): 5 x 256 regions = one per wavefront slot of the chip
+#endif
+constexpr uint32_t kRegionBlock = 256;      // = the workgroup size of the kernels
+constexpr uint32_t kBounceBatch = 64;
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define TRC_HOSTDEV __host__ __device__
+#else
+#define TRC_HOSTDEV
+#endif
+TRC_HOSTDEV inline uint32_t region_fill(uint32_t n_slots) {
+  const uint32_t per = (n_slots + kRegions - 1) / kRegions;
+  const uint32_t fill = (per + kRegionBlock - 1) / kRegionBlock * kRegionBlock;
+  return fill ? fill : kRegionBlock;
+}
+TRC_HOSTDEV inline uint32_t region_bpr(uint32_t n_slots) {
+  const uint32_t blocks = region_fill(n_slots) / kRegionBlock;
+  return blocks < (uint32_t)TRC_BOUNCE_BPR ? blocks : (uint32_t)TRC_BOUNCE_BPR;
+}
+TRC_HOSTDEV inline uint32_t region_cap(uint32_t n_slots) {
+  return ((region_fill(n_slots) / kRegionBlock + 3u * region_bpr(n_slots)) | 1u) * kRegionBlock;
+}
+// slots the state arrays (and the big-mesh key tables) of a launch sequence over n_slots paths hold
+inline size_t wavefront_slots(uint32_t n_slots) { return (size_t)kRegions * region_cap(n_slots); }
 
 // ---- big meshes (scene.h: kBigMeshTris): brute-force pass in front of a closest-hit kernel ------
 struct BigMesh {                    // host-side list, in big_slot order
@@ -116,8 +150,8 @@ void launch_intersect_rays(const FrameParams& fp, const float* rays6, uint32_t n
 // compact = false: state stays at its slot, dead paths flagged (pixel plane = -1).
 // compact = true : survivors are written densely into `next` behind a wave-ballot prefix sum;
 //                  per region (kRegions of them), one live count per bounce.
-// cur / next hold ntile * n_iters + kRegionSlack entries each, stage 3 * ntile * n_iters floats,
-// queue_count (kPathDepth + 1) * kRegions * kCountStride words.
+// cur / next hold wavefront_slots(ntile * n_iters) entries each, stage 3 * ntile * n_iters floats,
+// queue_count kQueueCountWords words.
 void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t iter_stride, uint32_t n_iters,
                             bool compact, PathState cur, PathState next, uint32_t* queue_count,
                             float* film, float* stage, DeviceCounters* counters, const BigMeshPass* bmp,

@@ -38,22 +38,31 @@ __device__ __forceinline__ v2f ldg2(const float2* p, size_t j) { return ((gptr<c
 __device__ __forceinline__ void stg4(float4* p, size_t j, float x, float y, float z, float w) { v4f v = { x, y, z, w }; ((gptr<v4f>)p)[j] = v; }
 __device__ __forceinline__ void stg2(float2* p, size_t j, float x, float y) { v2f v = { x, y }; ((gptr<v2f>)p)[j] = v; }
 
-// Wavefront pipelines: the path slots of a launch sequence are split into kRegions contiguous regions of
-// `cap` slots (a multiple of the workgroup size). A workgroup belongs to one region; survivors of a bounce
-// are compacted WITHIN their region (they can only become fewer), with one live count per region and
-// bounce, each in a 256-byte block of its own -- so the one-atomic-per-wavefront queue reservations of a
+// Wavefront pipelines: the path slots of a launch sequence are split into kRegions contiguous regions (kernels.h:
+// region_fill / region_cap). A workgroup belongs to one region; survivors of a bounce are compacted WITHIN their region,
+// with one live count per region and bounce, each in a 256-byte block of its own -- so the queue reservations of a
 // launch go to 256 addresses instead of one (same measurement as for the counters, kernels.h).
-__host__ __device__ inline uint32_t region_cap(uint32_t n_slots) {
-  const uint32_t per = (n_slots + kRegions - 1) / kRegions;
-  // an ODD number of 256-slot blocks: the regions advance side by side, and with a region stride of 2^16 x 75 bytes (the
-  // headline workload) the 256 wavefronts that work at the same offset of their regions met in the same memory channels
-  // (compacted pipeline 8.56 -> 8.36 ms)
-  const uint32_t cap = (((per + kBlock - 1) / kBlock) | 1u) * kBlock;
-  return cap ? cap : (uint32_t)kBlock;
+static_assert(kRegionBlock == (uint32_t)kBlock, "region blocks are workgroups");
+// Which paths a region starts with: the tasks (path numbers: iteration_in_chunk * ntile + pixel_in_tile) are dealt to the
+// regions 64 at a time, in rounds of kRegions tiles, and every round starts at another, scrambled region -- so that every
+// region holds the same mix of pixels. (Dealt one contiguous range each, the regions of the headline workload differed by
+// 13 % in the time they took: one covers the centre of the image twice, another the ceiling; dealt round robin, or with a
+// fixed turn per round, a region of a 512-wide image kept meeting the same columns and rows: 25 %.) Slot `off` of region p
+// starts as task region_task(p, off).
+static_assert((kRegions & (kRegions - 1u)) == 0u, "kRegions is a power of two");
+__device__ __forceinline__ uint32_t region_turn(uint32_t k) { return (k * 0x9E3779B1u) >> 20; }    // (scrambled, any width)
+__device__ __forceinline__ uint32_t region_task(uint32_t p, uint32_t off) {
+  const uint32_t k = off >> 6;
+  return (k * kRegions + ((p + region_turn(k)) & (kRegions - 1u))) * 64u + (off & 63u);
 }
-__device__ __forceinline__ uint32_t region_initial(uint32_t n_slots, uint32_t cap, uint32_t p) {
-  const uint32_t lo = p * cap;
-  return n_slots > lo ? (n_slots - lo < cap ? n_slots - lo : cap) : 0u;
+__device__ __forceinline__ uint32_t region_initial(uint32_t n_slots, uint32_t p) {
+  const uint32_t T = (n_slots + 63u) / 64u;                            // 64-task tiles in all
+  const uint32_t K = T / kRegions, R = T % kRegions;                    // full rounds, tiles of the last round
+  const uint32_t in_last = (p + region_turn(K)) & (kRegions - 1u);    // this region's place in round K
+  const uint32_t mine = K + ((in_last < R) ? 1u : 0u);
+  if (mine == 0u) return 0u;
+  const bool has_last = R ? (in_last == R - 1u) : (((p + region_turn(K - 1u)) & (kRegions - 1u)) == kRegions - 1u);
+  return (has_last && (n_slots & 63u)) ? (mine - 1u) * 64u + (n_slots & 63u) : mine * 64u;
 }
 // this workgroup's region, its first slot within the region, the region's live count
 struct RegionView { uint32_t p, first, n_in; };
@@ -62,7 +71,7 @@ __device__ __forceinline__ RegionView region_view(uint32_t n_slots, uint32_t cap
   RegionView v;
   v.p = blockIdx.x / bpr;
   v.first = (blockIdx.x - v.p * bpr) * kBlock;
-  v.n_in = count_in ? count_in[v.p * kCountStride] : region_initial(n_slots, cap, v.p);
+  v.n_in = count_in ? count_in[v.p * kCountStride] : region_initial(n_slots, v.p);
   return v;
 }
 
@@ -578,20 +587,23 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
                                                   uint32_t* __restrict__ queue_count, DeviceCounters* counters) {
   const uint32_t cap = region_cap(n_slots);
   const RegionView rv = region_view(n_slots, cap, nullptr);
-  const uint32_t idx = rv.p * cap + rv.first + threadIdx.x;    // slot; initially slot == task
+  const uint32_t idx = rv.p * cap + rv.first + threadIdx.x;    // slot
+  const uint32_t task = region_task(rv.p, rv.first + threadIdx.x);
   if (rv.first == 0 && threadIdx.x == 0) {
     queue_count[rv.p * kCountStride] = rv.n_in;
 #pragma unroll
     for (int d = 1; d <= kPathDepth; ++d) queue_count[(d * kRegions + rv.p) * kCountStride] = 0;
+#pragma unroll
+    for (int d = 0; d < kPathDepth; ++d) queue_count[kLiveCountWords + (d * kRegions + rv.p) * kCountStride] = 0;   // k_bounce's tile counters
   }
   const bool valid = rv.first + threadIdx.x < rv.n_in;
   if (valid) {
     uint32_t s;
-    const uint32_t itk = udivmod(idx, fp.div_tile, s);
+    const uint32_t itk = udivmod(task, fp.div_tile, s);
     Ray ray = camera_sample(fp, fp.pix0 + s, iter_first + itk * iter_stride);
     st.a[idx] = make_float4(ray.pos.x, ray.pos.y, ray.pos.z, ray.dir.x);
     st.b[idx] = make_float4(ray.dir.y, ray.dir.z, 1.0f, 1.0f);          // throughput (1, 1, 1): raytrace.cu:99
-    st.c[idx] = make_float2(1.0f, __int_as_float((int32_t)idx));        // :101
+    st.c[idx] = make_float2(1.0f, __int_as_float((int32_t)task));       // :101
   }
   count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, valid ? 1ull : 0ull);
 }
@@ -603,14 +615,11 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, uint32_t iter
 #ifndef TRC_BOUNCE_WAVES
 #define TRC_BOUNCE_WAVES 5         // resident waves per SIMD k_bounce is compiled for (6 = 80 VGPRs spills since the (ray, object) pairs)
 #endif
-// A workgroup walks its region's queue in steps of `bpr` workgroups (bpr = the workgroups per region of THIS launch,
-// capped by the launcher), so that the set-up -- the LDS copy of the DevXform table, the kernel arguments, the counters --
-// is paid once per workgroup and not once per 256 paths. Measured on the headline workload (512 workgroups per region
-// when every one takes 256 paths = 11.53 ms): cap 5 / 10 / 20 -> 12.5 / 12.6 / 11.7 ms (a wavefront's trips are serial:
-// load the state, trace, store -- too few of them in flight to hide the HBM latency), 40 / 80 -> 11.31, 160 -> 11.72.
-#ifndef TRC_BOUNCE_BPR
-#define TRC_BOUNCE_BPR 64
-#endif
+// `bpr` persistent workgroups per region (as many as stay resident: 5 x 256 CUs / 256 regions); their wavefronts take
+// the region's queue 64 slots at a time from the region's grab counter, so that a launch ends within one trip of its last
+// wavefront (statically divided, the 16384 workgroups of a launch drained for 1/13 of its duration: mean occupancy 4.3 of 5
+// wavefronts per SIMD) and the set-up -- the LDS tables, the kernel arguments, the counters -- is paid 1280 times per launch.
+// The tile after the next one is reserved while the current one is traced (`decided`), so no trip waits for its reservation.
 // All of k_bounce's arguments as one struct (FrameParams first: kernarg_params()), for the same reason as k_queue's: a loop
 // that keeps 68 dwords of FrameParams, twenty state pointers and the rest in SGPRs leaves too few for its body, and the
 // overflow lives in VGPR lanes -- round 2's k_bounce had 75-90 spilled SGPRs (every reload a v_readlane) and ran the same
@@ -622,20 +631,33 @@ struct BounceArgs {
   int depth;
   PathState cur, next;
   const uint32_t* count_in; uint32_t* count_out;
+  uint32_t* grab;                     // this bounce's tile counters, one per region (kCountStride words apart, zero at launch)
   float* stage; DeviceCounters* counters;
 };
 static_assert(offsetof(BounceArgs, fp) == 0, "kernarg_params() reads the FrameParams at offset 0 of the kernel-argument segment");
 __device__ __forceinline__ const BounceArgs* kernarg_bounce() { return reinterpret_cast<const BounceArgs*>(kernarg_params()); }
 
+#ifdef TRC_BOUNCE_TRACE      // development build (tools/bounce_trace.py): when did every workgroup of every bounce start and end?
+__device__ unsigned long long g_bounce_trace[kPathDepth * 32768 * 2];
+} // namespace trc
+extern "C" int trc_debug_bounce_trace(unsigned long long* dst, size_t n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(trc::g_bounce_trace), n * sizeof(unsigned long long));
+}
+namespace trc {
+#endif
 template <bool COMPACT, bool LDS_GATHER, bool FIRST>
 __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs a) {
+#ifdef TRC_BOUNCE_TRACE
+  const unsigned long long trace_t0 = wall_clock64();
+#endif
   const FrameParams& fp = a.fp;
   const uint32_t cap = region_cap(a.n_slots);
-  const uint32_t bpr = a.bpr;
-  const uint32_t p = blockIdx.x / bpr;                                // this workgroup's region
-  const uint32_t n_in = (COMPACT && !FIRST) ? a.count_in[p * kCountStride] : region_initial(a.n_slots, cap, p);
-  uint32_t first = (blockIdx.x - p * bpr) * kBlock;
-  if (first >= n_in) return;                                          // whole block past its region's queue
+  // this workgroup's region: workgroups p, p + 256, ... A SIMD issues its oldest wavefront first, so the workgroups placed
+  // first (the lowest numbers: one per CU, then a second one per CU ...) run fastest -- 1.24 against 2.2 ms until the end
+  // of one bounce with five resident generations -- and a region must own some of every generation to keep pace with the rest
+  const uint32_t p = (blockIdx.x + blockIdx.x / kRegions) % kRegions;   // (+ generation: and some on every XCD)
+  const uint32_t n_in = (COMPACT && !FIRST) ? a.count_in[p * kCountStride] : region_initial(a.n_slots, p);
+  if (n_in == 0) return;                                              // (whole block: its region's queue is empty)
   __shared__ DevXform s_xf[kGatherMax ? kGatherMax : 1];              // as in k_queue: table of the held candidates' gathers
   __shared__ DevMaterial s_mat[kGatherMax ? kGatherMax : 1];          // and the materials (indexed by original object index)
   if (LDS_GATHER) {
@@ -646,29 +668,48 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
     __syncthreads();
   }
   const uint32_t region_base = p * cap;
-  const uint32_t step = bpr * kBlock;
+  const uint32_t n_tiles = (n_in + 63u) / 64u;
   const int depth = a.depth;
+  const unsigned lane = lane_id();
   uint32_t tt = 0, n_live = 0, n_paths = 0;
   // A trip's ray state as it sits in memory. The loads of trip n + 1 are issued in the middle of trip n (bounce_step's
   // `decided` hook: ~300 instructions ahead of their use) instead of in front of an idle wavefront.
   struct State { int32_t task; float px, py, pz, dx, dy, dz, cr, cg, cb; };
-  auto load_state = [&](uint32_t f) -> State {
+  auto load_state = [&](uint32_t tile_) -> State {
     State L; L.task = -1; L.px = L.py = L.pz = L.dx = L.dy = L.dz = L.cr = L.cg = L.cb = 0.0f;
-    if (FIRST || f >= n_in) return L;                                 // (wave-uniform)
+    if (FIRST || tile_ >= n_tiles) return L;                          // (wave-uniform)
     const PathState cur = load_uniform(&kernarg_bounce()->cur);
-    if (f + threadIdx.x < n_in) {
-      const uint32_t j = region_base + f + threadIdx.x;
+    if (tile_ * 64u + lane < n_in) {
+      const uint32_t j = region_base + tile_ * 64u + lane;
       const v4f A = ldg4(cur.a, j), B = ldg4(cur.b, j);
       const v2f Cc = ldg2(cur.c, j);
-      L.task = __float_as_int(Cc.y);                                  // -1 once the path ended (raytrace.cu:119-124)
+      L.task = __float_as_int(Cc.y);                                  // -1: the path ended (raytrace.cu:119-124) or a dead slot
       L.px = A.x; L.py = A.y; L.pz = A.z; L.dx = A.w; L.dy = B.x; L.dz = B.y; L.cr = B.z; L.cg = B.w; L.cb = Cc.x;
     }
     return L;
   };
-  State st = load_state(first);
-  for (; first < n_in; first += step) {
-    const uint32_t i = region_base + first + threadIdx.x;
-    const bool in_queue = first + threadIdx.x < n_in;
+  // Reservations -- of the tiles a wavefront takes from its region's queue, and of its place in the next queue, kBounceBatch
+  // slots at a time -- are atomics at the memory side, microseconds away. Each is made a whole trip before its answer is
+  // needed: a wavefront holds the tile it traces, the next one (whose state it prefetches) and a pending third; the batch
+  // it is filling and a pending second one. Their answers sit in lane 0 of `tile_after_v` / `out_next_v`.
+  uint32_t tile, tile_next, out_off = 0, out_rem = 0;
+  unsigned tile_after_v, out_next_v = 0;
+  {
+    unsigned v = 0, w = 0;
+    if (lane == 0) {
+      v = __hip_atomic_fetch_add(as_global(a.grab) + p * kCountStride, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (COMPACT) w = __hip_atomic_fetch_add(as_global(a.count_out) + p * kCountStride, 2u * kBounceBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    tile = __builtin_amdgcn_readfirstlane(v);
+    tile_next = tile + 1u;
+    tile_after_v = v + 2u;
+    if (COMPACT) { out_off = __builtin_amdgcn_readfirstlane(w); out_rem = kBounceBatch; out_next_v = w + kBounceBatch; }
+  }
+  State st = load_state(tile);
+  while (tile < n_tiles) {
+    const uint32_t first = tile * 64u;
+    const uint32_t i = region_base + first + lane;                    // slot
+    const bool in_queue = first + lane < n_in;
     int32_t task = -1;
     Ray ray; ray.pos = splat3(0.0f); ray.dir = splat3(0.0f);
     f3 col = splat3(0.0f);
@@ -676,7 +717,7 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
     {
       const BounceArgs* ka = kernarg_bounce();
       if (FIRST) {
-        task = in_queue ? (int32_t)i : -1;                            // initially slot == task (raytrace.cu:101)
+        task = in_queue ? (int32_t)region_task(p, first + lane) : -1;  // raytrace.cu:101
       } else {
         task = st.task;
         ray.pos = mk3(st.px, st.py, st.pz);
@@ -695,31 +736,27 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
         n_paths += active0 ? 1u : 0u;
       }
     }
-    const uint32_t first_next = first + step;
-    // Once the outcome of the trip is known (bounce_step: `decided`): compaction by wavefront ballot -- rank within the
-    // wave from the ballot mask, one atomic per wave reserves a contiguous run in the next queue -- and the loads of the
-    // next trip's state (past the queue's end: an empty state, no loads). The vector-memory counter is in order, so the
-    // ONE wait of a trip (for the atomic's answer, after the shading) covers the loads too, and every store of the trip
-    // is issued after it: nothing waits for a store.
-    const unsigned lane = lane_id();
+    // Once the outcome of the trip is known (bounce_step: `decided`): who survives (compaction by wavefront ballot: rank
+    // within the wave from the ballot mask), and the loads of the next trip's state (past the queue's end: an empty state,
+    // no loads). The vector-memory counter is in order, so the ONE wait of a trip -- after the shading, for these loads and
+    // for last trip's reservations -- comes before every store of the trip: nothing waits for a store.
     unsigned long long mask = 0ull;
-    unsigned base_v = 0;
     auto decided = [&](bool cont_) {
-      if (COMPACT) {
-        mask = __ballot(cont_);
-        const unsigned total = __popcll(mask);
-        if (lane == 0 && total) base_v = __hip_atomic_fetch_add(as_global(load_uniform(&kernarg_bounce()->count_out)) + p * kCountStride, total,
-                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (!FIRST) st = load_state(first_next);
+      if (COMPACT) mask = __ballot(cont_);
+      if (!FIRST) st = load_state(tile_next);
     };
     const bool active = task >= 0;                                    // raytrace.cu:119-124
     const int res = LDS_GATHER ? bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, s_xf, true, true, true, decided, s_mat, true)
                                : bounce_step(fp, active, pixel, iter, depth, ray, col, tt, i, fp.sc.xf, true, true, false, decided);
     const bool cont = (res == STEP_CONTINUE);
-    const unsigned base = __builtin_amdgcn_readfirstlane(base_v);     // (waits for the atomic, and with it for the loads)
-    if (!FIRST && !COMPACT) asm volatile("" :: "v"(st.pz), "v"(st.cg), "v"(st.task));   // the same wait where there is no atomic
+    const uint32_t tile_after = __builtin_amdgcn_readfirstlane(tile_after_v);          // (the wait)
+    const uint32_t out_next = COMPACT ? (uint32_t)__builtin_amdgcn_readfirstlane(out_next_v) : 0u;
+    if (!FIRST) asm volatile("" :: "v"(st.pz), "v"(st.cg), "v"(st.task));
     const BounceArgs* ka = kernarg_bounce();
+    if (tile_after < n_tiles) {                                       // (wave-uniform; past the end nothing is left to reserve)
+      if (lane == 0) tile_after_v = __hip_atomic_fetch_add(as_global(load_uniform(&ka->grab)) + p * kCountStride, 1u,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (res == STEP_LIGHT || res == STEP_BLACK) {
       // Every path writes its sample when it ends -- the radiance it carried to the light, or the zero that bounce_step()
       // left in `col` for a miss or the depth cap -- exactly once per slot of the chunk, as k_queue does: the staging
@@ -728,13 +765,22 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
       dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
     }
     if (COMPACT) {
+      const unsigned total = __popcll(mask);
       if (cont) {
         const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
-        const uint32_t j = region_base + base + rank;
+        const uint32_t j = region_base + (rank < out_rem ? out_off + rank : out_next + (rank - out_rem));
         const PathState next = load_uniform(&ka->next);
         stg4(next.a, j, ray.pos.x, ray.pos.y, ray.pos.z, ray.dir.x);
         stg4(next.b, j, ray.dir.y, ray.dir.z, col.x, col.y);
         stg2(next.c, j, col.z, __int_as_float(task));
+      }
+      if (total >= out_rem) {                                         // batch full: go on in the next one, reserve another
+        out_off = out_next + (total - out_rem);
+        out_rem = kBounceBatch - (total - out_rem);                   // (total <= 64 = kBounceBatch: at least one slot is left)
+        if (lane == 0) out_next_v = __hip_atomic_fetch_add(as_global(load_uniform(&ka->count_out)) + p * kCountStride, kBounceBatch,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        out_off += total; out_rem -= total;
       }
     } else if (active) {
       const PathState cur = load_uniform(&ka->cur);
@@ -747,11 +793,27 @@ __global__ __launch_bounds__(kBlock, TRC_BOUNCE_WAVES) void k_bounce(BounceArgs 
       }
     }
     n_live += active ? 1u : 0u;
+    tile = tile_next; tile_next = tile_after;
+  }
+  if (COMPACT) {
+    // what this wavefront reserved in the next queue and did not fill: dead slots (no path: task -1)
+    const uint32_t out_next = (uint32_t)__builtin_amdgcn_readfirstlane(out_next_v);
+    const PathState next = load_uniform(&kernarg_bounce()->next);
+    if (lane < out_rem) stg2(next.c, region_base + out_off + lane, 0.0f, __int_as_float(-1));
+    static_assert(kBounceBatch == 64u, "one lane per slot of a batch");
+    stg2(next.c, region_base + out_next + lane, 0.0f, __int_as_float(-1));
   }
   DeviceCounters* counters = load_uniform(&kernarg_bounce()->counters);
   if (FIRST) count_add(&counters->bank[blockIdx.x % kCounterBanks].paths, (unsigned long long)n_paths);
   count_add(&counters->bank[blockIdx.x % kCounterBanks].live_segments, (unsigned long long)n_live);
   count_add(&counters->bank[blockIdx.x % kCounterBanks].tri_tests, (unsigned long long)tt);
+#ifdef TRC_BOUNCE_TRACE
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 32768u) {
+    g_bounce_trace[((size_t)depth * 32768u + blockIdx.x) * 2u] = trace_t0;
+    g_bounce_trace[((size_t)depth * 32768u + blockIdx.x) * 2u + 1u] = wall_clock64();
+  }
+#endif
 }
 
 // ---- fused persistent pipeline ------------------------------------------------------------------
@@ -1083,12 +1145,11 @@ void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t
   // (no clearing of `stage`: k_bounce writes the sample of every path of the chunk when the path ends)
   // the depth-0 bounce generates the camera rays itself unless a big-mesh pass has to see them in memory first
   const bool fold_raygen = (bmp == nullptr);
-  if (fold_raygen) (void)hipMemsetAsync(queue_count, 0, sizeof(uint32_t) * (kPathDepth + 1) * kRegions * kCountStride, stream);
+  if (fold_raygen) (void)hipMemsetAsync(queue_count, 0, sizeof(uint32_t) * kQueueCountWords, stream);
   else hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, fp, iter_first, iter_stride, n_slots, cur, queue_count, counters);
   const bool lds = gather_records(fp.sc) <= kGatherMax;
-  // k_bounce: at most TRC_BOUNCE_BPR workgroups per region, each walking the region's queue in that stride
-  const uint32_t bpr_full = region_cap(n_slots) / kBlock;
-  const uint32_t bpr = bpr_full < (uint32_t)TRC_BOUNCE_BPR ? bpr_full : (uint32_t)TRC_BOUNCE_BPR;
+  // k_bounce: at most TRC_BOUNCE_BPR workgroups per region, their wavefronts taking the region's queue tile by tile
+  const uint32_t bpr = region_bpr(n_slots);
   const dim3 bgrid(kRegions * bpr);
   for (int d = 0; d < kPathDepth; ++d) {
     if (bmp) launch_big_mesh_passes<1>(fp, n_slots, cur, compact ? queue_count + d * kRegions * kCountStride : nullptr, *bmp, stream);
@@ -1098,7 +1159,7 @@ void launch_wavefront_chunk(const FrameParams& fp, uint32_t iter_first, uint32_t
     const PathState out = compact ? next : cur;
     BounceArgs ba;
     ba.fp = fp; ba.iter_first = iter_first; ba.iter_stride = iter_stride; ba.n_slots = n_slots; ba.bpr = bpr; ba.depth = d;
-    ba.cur = cur; ba.next = out; ba.count_in = cin; ba.count_out = cout; ba.stage = stage; ba.counters = counters;
+    ba.cur = cur; ba.next = out; ba.count_in = cin; ba.count_out = cout; ba.grab = queue_count + kLiveCountWords + d * kRegions * kCountStride; ba.stage = stage; ba.counters = counters;
 #define TRC_LAUNCH_BOUNCE(C, L, F) hipLaunchKernelGGL((k_bounce<C, L, F>), bgrid, block, 0, stream, ba)
     if (compact) { if (lds) { if (first) TRC_LAUNCH_BOUNCE(true, true, true); else TRC_LAUNCH_BOUNCE(true, true, false); }
                    else     { if (first) TRC_LAUNCH_BOUNCE(true, false, true); else TRC_LAUNCH_BOUNCE(true, false, false); } }

@@ -179,7 +179,7 @@ int ensure_wavefront_state(trc_ctx* c, bool need_second, size_t slots) {
     PathState& s = c->state[b];
     s.a = (float4*)p; s.b = (float4*)(p + 4ull * n); s.c = (float2*)(p + 8ull * n);      // 16 + 16 + 8 bytes per slot
   }
-  if (!c->queue_count) HIP_TRY(hipMalloc((void**)&c->queue_count, sizeof(uint32_t) * (kPathDepth + 1) * kRegions * kCountStride));
+  if (!c->queue_count) HIP_TRY(hipMalloc((void**)&c->queue_count, sizeof(uint32_t) * kQueueCountWords));
   return TRC_OK;
 }
 
@@ -716,7 +716,7 @@ int trc_pathtrace(trc_ctx* c, const trc_camera* cam, uint64_t seed,
     }
   }
   if (wave) {
-    const size_t slots = (size_t)fp.ntile * chunk_iters + kRegionSlack;
+    const size_t slots = wavefront_slots(fp.ntile * chunk_iters);
     int rc = ensure_wavefront_state(c, pipeline == TRC_PIPE_COMPACTED, slots); if (rc) return rc;
     rc = ensure_big_mesh_buffers(c, slots); if (rc) return rc;
     if (!c->big.empty()) {
