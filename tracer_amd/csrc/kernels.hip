@@ -333,6 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t m
   }
 }
 
+constexpr uint32_t kMeshItemWord = 16;   // MeshRayQueue::count[kMeshItemWord]: next work item of k_mesh_brute (64 spare words follow the count)
 constexpr int kRaysPerLane = 2;    // rays a lane of k_mesh_brute carries: every LDS broadcast of a triangle record
                                    // (48 B x 64 lanes through the LDS return path) then feeds two tests
 constexpr uint32_t kBruteRays = kBlock * kRaysPerLane;   // rays per work item
@@ -363,7 +364,16 @@ __global__ __launch_bounds__(kBlock) void k_mesh_brute(MeshRayQueue q, const Hot
   const uint32_t nq = *q.count;
   const uint32_t n_rb = (nq + kBruteRays - 1) / kBruteRays;
   const uint32_t n_items = n_rb * n_segs;
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+  // Work items are taken from a counter (the word 16 behind the queue's count, zeroed with it), not dealt out by block
+  // number: a SIMD issues its oldest wavefront first, so of the 8 workgroups a CU holds the first placed run fastest, and
+  // with equal shares the launch waited for the last placed.
+  __shared__ uint32_t s_item;
+  while (true) {
+    __syncthreads();                                       // (everyone has read the previous item number)
+    if (threadIdx.x == 0) s_item = atomicAdd(q.count + kMeshItemWord, 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= n_items) break;
     const uint32_t seg = item / n_rb;
     const uint32_t rb = item - seg * n_rb;
     // Lanes past the end of the queue carry a zero ray: det == 0, "certain" for every triangle.
@@ -1098,10 +1108,13 @@ static void launch_big_mesh_passes(const FrameParams& fp, uint32_t n_slots, Path
     const BigMesh& m = bmp.big[b];
     const uint32_t n_tiles = (m.tri_count + kMeshTile - 1) / kMeshTile;
     // segments of >= 16 tiles (the 256 rays of a work item are loaded once per segment), at most 64 of them
-    uint32_t tiles_per_seg = (n_tiles + 63u) / 64u;
+#ifndef TRC_MESH_SEGS
+#define TRC_MESH_SEGS 256        // (64 -> 128 -> 256 segments: 70.4 -> 70.1 -> 69.7 ms on configs[4]: the launch ends within one item of its last workgroup)
+#endif
+    uint32_t tiles_per_seg = (n_tiles + (TRC_MESH_SEGS - 1u)) / (uint32_t)TRC_MESH_SEGS;
     if (tiles_per_seg < 16u) tiles_per_seg = 16u;
     const uint32_t n_segs = (n_tiles + tiles_per_seg - 1) / tiles_per_seg;
-    (void)hipMemsetAsync(bmp.q.count, 0, sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(bmp.q.count, 0, sizeof(uint32_t) * (kMeshItemWord + 1u), stream);   // count and k_mesh_brute's item counter
     hipLaunchKernelGGL(k_mesh_rays<SOURCE>, dim3(SOURCE == 1 ? kRegions * (region_cap(n_slots) / kBlock) : grid_for(n_slots)), dim3(kBlock), 0, stream,
                        fp, m.mesh_index, n_slots, cur, count_in, bmp.q, bmp.keys, rays6);
     if (bmp.bvh && bmp.bvh[b].nodes) {
