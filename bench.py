@@ -47,17 +47,23 @@ BYTES_PER_SEGMENT_REF = 108.0  # reference buffer layout, SURVEY.md 8(d)
 PEAK_FP32_TFLOPS = 157.3       # MI355X FP32 vector peak: v_pk_fma_f32, packed AND fused (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 N_SIMD = 1024                  # 256 CUs x 4
-# ONE issue-cost constant (tools/micro/issue_rate.hip, bank.hip, placement.hip on MI355X): a SIMD accepts one wave64
-# v_add_f32 / v_mul_f32 / v_fma_f32 every 2.5 shader cycles from two or more resident waves (5.0 from one wave alone),
-# whatever the register banks. The numerical contract (-ffp-contract=off) allows no fusing, so the ceiling of this path
-# is one add-or-multiply per lane per 2.5 cycles.
+# Two issue-cost constants, every utilisation below is printed against BOTH, labelled:
+#   2.5 cycles per wave64 instruction: tools/micro/issue_rate.hip on this chip -- streams of independent v_add_f32 /
+#       v_mul_f32 / v_mov_b32 issue at 5.0 cycles from one wave and 2.5 per SIMD from two, and (round 3,
+#       profiles/r03_issue_rate_occupancy.txt) stay at 2.5 by the wall clock at 4, 6 and 8 resident waves: a SIMD serves its
+#       two oldest wavefronts and the younger ones wait (3 waves take as long as 4). Mixed streams reach 2.3 at 8 waves.
+#   2.0 cycles: the microarchitecture guide's figure (MI355X_MICROARCH.md, constants table). k_mesh_brute<false> -- unfused
+#       multiplies, adds, compares and LDS broadcasts, 6.9 resident waves per SIMD -- sustains 2.07 by the PMC counters
+#       (profiles/r03_c_mesh_pmc.json), so 2.5 is NOT a hard floor for a real instruction mix: price against 2.0.
+# The numerical contract (-ffp-contract=off) allows no fusing, so the ceiling of this path is one add-or-multiply per lane
+# per issue slot.
 VALU_ISSUE_CYCLES = 2.5
-# The microarchitecture guide's figure for the same thing (MI355X_MICROARCH.md, constants table: v_fma_f32 with >= 2 waves).
-# Every utilisation below is printed against BOTH constants, labelled.
 VALU_ISSUE_CYCLES_GUIDE = 2.0
 ISSUE_CONSTANTS = (("measured_2.5_cycles_per_wave64_inst", VALU_ISSUE_CYCLES), ("guide_2.0_cycles_per_wave64_inst", VALU_ISSUE_CYCLES_GUIDE))
-ISSUE_CONSTANT_SOURCES = {"measured_2.5_cycles_per_wave64_inst": "tools/micro/issue_rate.hip on this chip (profiles/r02_issue_rate.txt)",
-                          "guide_2.0_cycles_per_wave64_inst": "/opt/skills/guides/MI355X_MICROARCH.md, constants table"}
+ISSUE_CONSTANT_SOURCES = {"measured_2.5_cycles_per_wave64_inst": "tools/micro/issue_rate.hip on this chip, single-instruction streams at 2 to 8 waves per SIMD "
+                                                                 "(profiles/r02_issue_rate.txt, profiles/r03_issue_rate_occupancy.txt); not a hard floor: "
+                                                                 "k_mesh_brute<false> sustains 2.07 (profiles/r03_c_mesh_pmc.json)",
+                          "guide_2.0_cycles_per_wave64_inst": "/opt/skills/guides/MI355X_MICROARCH.md, constants table: the bound to price against"}
 C4_W, C4_H, C4_TOTAL_ITERS = 3840, 2160, 512      # config4_strong: an eighth of configs[3]'s 4096 samples per pixel
 
 
@@ -325,34 +331,43 @@ def extra_configs(ta, k_queue_ms=None):
             # the exit-stage costs of SURVEY.md 8(d) (20 / 30 / 46 / 74) weighted by the exit rates the oracle counted on this
             # frame. The kernel is issue-bound: instructions per pair from the committed PMC pass, clock from its own wavefronts.
             prof, rates = mesh_profile()
-            rl = {"bound": "valu", "kernel": "k_mesh_brute<%s>" % ("true" if accel == 0 else "false")}
-            if rates:
-                fpp = float(rates["flop_per_pair_weighted"])
-                tf = pairs * fpp / (k_min * 1e-3) / 1e12
-                rl.update({"achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
-                           "flop_per_pair": round(fpp, 3), "flop_per_pair_source": rates["_file"],
-                           "exit_rates_Ray.inl_196_203_208_none": [round(rates["exit_rates"][k], 8) for k in ("det", "bary_x", "bary_y", "full")],
-                           "note": "reference flop per pair = exit-stage costs 20/30/46/74 (SURVEY.md 8d) weighted by where Ray.inl:189-226 "
-                                   "leaves on this frame; the frame time also holds k_mesh_rays and k_raytrace1 (< 1 %). This is the "
-                                   "REFERENCE's arithmetic per unit of time, not what the kernel issues: with mesh_accel 0 nearly every pair "
-                                   "is decided by a 10-instruction conservative bounding-sphere test (same hits, bit for bit), so the figure "
-                                   "says how fast the reference's work gets done; how busy the VALU is says valu_issue_utilisation"})
+            rl = {"bound": "valu issue", "kernel": "k_mesh_brute<%s>" % ("true" if accel == 0 else "false")}
             p = (prof or {}).get("by_mesh_accel", {}).get(str(accel))
             mhz = cnt.get("shader_mhz")
             if p:
-                # instructions AND cycles of the same profiled launch (GRBM_GUI_ACTIVE / 8): self-consistent, whatever the
-                # clock did between this run and that one -- the kernel stands on the issue floor, so a 2 % clock difference
-                # between two runs would otherwise decide on which side of 1.0 the figure lands
-                rl["valu_insts_per_64_pairs"] = round(p["valu_insts_per_64_pairs"], 3)      # = per-lane instructions per pair
+                # What the kernel EXECUTES against what the SIMDs can issue: per-lane VALU instructions per pair from the
+                # committed PMC pass, and instructions AND cycles of that same profiled launch (GRBM_GUI_ACTIVE / 8) for the
+                # fraction -- self-consistent, whatever the clock did between this run and that one. Peak: one wave64
+                # instruction per SIMD per 2.0 cycles (the guide's constant; bench.py's header on why not 2.5).
+                ipp = p["valu_insts_per_64_pairs"]                                           # = per-lane instructions per pair
+                clk = (mhz or 0.0) * 1e6
+                rl.update({"achieved": round(pairs * ipp / (k_min * 1e-3) / 1e12, 3),
+                           "peak": round(64.0 * N_SIMD * clk / VALU_ISSUE_CYCLES_GUIDE / 1e12, 3) if clk else None,
+                           "unit": "T lane-instructions/s (VALU, executed)",
+                           "frac": round(VALU_ISSUE_CYCLES_GUIDE / p["simd_cycles_per_valu_inst"], 4),
+                           "frac_source": "VALU wave-instructions and shader cycles of the profiled launch (%s)" % prof["_file"]})
+                rl["valu_insts_per_64_pairs"] = round(ipp, 3)
                 rl["simd_cycles_per_valu_inst"] = round(p["simd_cycles_per_valu_inst"], 4)
                 rl["valu_issue_utilisation"] = {name: round(c / p["simd_cycles_per_valu_inst"], 4) for name, c in ISSUE_CONSTANTS}
                 rl["issue_constants"] = ISSUE_CONSTANT_SOURCES
+                rl["wave_occupancy_mean_waves_per_simd"] = round(p.get("wave_occupancy_mean_waves_per_simd", 0.0), 2)
                 rl["valu_insts_source"] = prof["_file"]
                 rl["valu_insts_profile_matches_run"] = bool(p["pairs_per_frame"] == pairs and prof.get("kernel_source_digest") == kernel_source_digest())
                 rl["frame_shader_cycles_in_profile"] = round(p["shader_cycles_per_dispatch"])
                 if mhz:
                     rl["shader_mhz"] = round(mhz, 1)
                     rl["frame_shader_cycles_live"] = round(k_min * 1e-3 * mhz * 1e6)
+            if rates:
+                fpp = float(rates["flop_per_pair_weighted"])
+                tf = pairs * fpp / (k_min * 1e-3) / 1e12
+                e["reference_arithmetic"] = {
+                    "tflops_equivalent": round(tf, 2), "flop_per_pair": round(fpp, 3), "flop_per_pair_source": rates["_file"],
+                    "exit_rates_Ray.inl_196_203_208_none": [round(rates["exit_rates"][k], 8) for k in ("det", "bary_x", "bary_y", "full")],
+                    "note": "how fast the REFERENCE's arithmetic gets done, not what the kernel issues: flop per pair = exit-stage costs "
+                            "20/30/46/74 (SURVEY.md 8d) weighted by where Ray.inl:189-226 leaves on this frame. With mesh_accel 0 nearly "
+                            "every pair is decided by a conservative bounding-sphere test of about ten instructions (same hits, bit for "
+                            "bit), so this figure may exceed the FP32 peak and is no roofline fraction; the roofline object prices the "
+                            "instructions the kernel executes. The frame time also holds k_mesh_rays and k_raytrace1 (< 1 %)."}
             e["roofline"] = rl
         out.append(e)
     tr.close()

@@ -322,11 +322,16 @@ template <int C> void run(int waves_per_simd, int n_cu) {
 }
 
 template <int C> void all(int n_cu) { for (int w : {1, 2, 4}) run<C>(w, n_cu); }
+template <int C> void occupancy(int n_cu) { for (int w : {1, 2, 3, 4, 5, 6, 7, 8}) run<C>(w, n_cu); }
 
 int main(int argc, char** argv) {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   const int n = p.multiProcessorCount;
   printf("device %s, %d CUs\n", p.name, n);
+  if (argc > 1 && argv[1][0] == 'o') {      // "occ": the plain arithmetic at 1 .. 8 resident waves per SIMD
+    occupancy<ADD>(n); occupancy<MUL>(n); occupancy<ADDMUL>(n); occupancy<FMA3>(n); occupancy<MOV>(n); occupancy<MIX_CMP>(n);
+    return 0;
+  }
   all<MAD_U64>(n); all<MIX_MAD_U64>(n); all<MIX_CND_SGPR>(n); all<MIX_CND_SGPR1>(n);
   if (argc > 2) return 0;                  // two arguments: only the 64-bit multiply-add
   all<MIX_PK1>(n); all<MIX_PK3>(n); all<MIX_PK_2OF3>(n); all<PKADD>(n); all<MIX_PKADD1>(n);
