@@ -54,7 +54,7 @@ N_SIMD = 1024                  # 256 CUs x 4
 #       two oldest wavefronts and the younger ones wait (3 waves take as long as 4). Mixed streams reach 2.3 at 8 waves.
 #   2.0 cycles: the microarchitecture guide's figure (MI355X_MICROARCH.md, constants table). k_mesh_brute<false> -- unfused
 #       multiplies, adds, compares and LDS broadcasts, 6.9 resident waves per SIMD -- sustains 2.07 by the PMC counters
-#       (profiles/r03_c_mesh_pmc.json), so 2.5 is NOT a hard floor for a real instruction mix: price against 2.0.
+#       (profiles/r03_d_mesh_pmc.json), so 2.5 is NOT a hard floor for a real instruction mix: price against 2.0.
 # The numerical contract (-ffp-contract=off) allows no fusing, so the ceiling of this path is one add-or-multiply per lane
 # per issue slot.
 VALU_ISSUE_CYCLES = 2.5
@@ -62,7 +62,7 @@ VALU_ISSUE_CYCLES_GUIDE = 2.0
 ISSUE_CONSTANTS = (("measured_2.5_cycles_per_wave64_inst", VALU_ISSUE_CYCLES), ("guide_2.0_cycles_per_wave64_inst", VALU_ISSUE_CYCLES_GUIDE))
 ISSUE_CONSTANT_SOURCES = {"measured_2.5_cycles_per_wave64_inst": "tools/micro/issue_rate.hip on this chip, single-instruction streams at 2 to 8 waves per SIMD "
                                                                  "(profiles/r02_issue_rate.txt, profiles/r03_issue_rate_occupancy.txt); not a hard floor: "
-                                                                 "k_mesh_brute<false> sustains 2.07 (profiles/r03_c_mesh_pmc.json)",
+                                                                 "k_mesh_brute<false> sustains 2.07 (profiles/r03_d_mesh_pmc.json)",
                           "guide_2.0_cycles_per_wave64_inst": "/opt/skills/guides/MI355X_MICROARCH.md, constants table: the bound to price against"}
 C4_W, C4_H, C4_TOTAL_ITERS = 3840, 2160, 512      # config4_strong: an eighth of configs[3]'s 4096 samples per pixel
 

@@ -334,8 +334,11 @@ __global__ __launch_bounds__(kBlock) void k_mesh_rays(FrameParams fp, uint32_t m
 }
 
 constexpr uint32_t kMeshItemWord = 16;   // MeshRayQueue::count[kMeshItemWord]: next work item of k_mesh_brute (64 spare words follow the count)
-constexpr int kRaysPerLane = 2;    // rays a lane of k_mesh_brute carries: every LDS broadcast of a triangle record
-                                   // (48 B x 64 lanes through the LDS return path) then feeds two tests
+#ifndef TRC_RAYS_PER_LANE
+#define TRC_RAYS_PER_LANE 4          // 2 / 3 / 4 / 6 / 8 rays per lane: 68.6 / 65.4 / 64.0-65.4 / 65.4 / 71.0 ms on configs[4] (107 VGPRs at 4: four waves per SIMD, more independent work in each)
+#endif
+constexpr int kRaysPerLane = TRC_RAYS_PER_LANE;    // rays a lane of k_mesh_brute carries: every LDS broadcast of a triangle record
+                                   // (48 B x 64 lanes through the LDS return path) then feeds that many tests
 constexpr uint32_t kBruteRays = kBlock * kRaysPerLane;   // rays per work item
 
 // BOUND: a bounding-sphere pre-test in front of all that (meshes whose faces are small against the mesh, BigMesh::
